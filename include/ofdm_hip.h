@@ -1,0 +1,210 @@
+/*
+ * ofdm_hip.h -- C ABI of libofdm_hip.so, the MI355X (gfx950) OFDM TX/RX engine.
+ *
+ * This is the drop-in boundary for the ofdm_mod / ofdm_demod hot path of
+ * rubiruchi/ofdm_uhd.  The reference reaches its DSP through SWIG proxies of
+ * GNU Radio 3.6 blocks (digital_swig.py); each entry point below names the
+ * reference interface it replaces.  Plain C types only: pointers, sizes and
+ * one POD configuration struct -- no torch / C++ types.
+ *
+ * Conventions
+ *   - every function returns 0 (OFDM_OK) or a negative OFDM_E_* code; the
+ *     message is available from ofdm_last_error().
+ *   - bulk data pointers (payload bytes, IQ samples) are DEVICE pointers when
+ *     the handle was created with OFDM_F_DEVICE_PTRS, host pointers otherwise.
+ *     Small metadata arrays (offsets, lengths, flags, counters) are always
+ *     HOST pointers.
+ *   - a handle is single-owner (not thread-safe) and bound to one GPU and one
+ *     HIP stream.  Calls return after the stream has drained unless stated.
+ *   - IQ samples are interleaved float32 (I,Q) = gr_complex, the format of
+ *     gr.file_sink(gr.sizeof_gr_complex, ...) (ofdm.py:124-131).
+ */
+#ifndef OFDM_HIP_H
+#define OFDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFDM_ABI_VERSION 1
+
+#define OFDM_MAX_FFT 4096
+#define OFDM_MAX_TAPS 512
+#define OFDM_MAX_ARITY 256
+#define OFDM_MASK_LEN 4096      /* len(random_mask_tuple), ofdm_packet_utils.py:195 */
+#define OFDM_MAX_PKT_LEN 4096   /* MAX_PKT_LEN of digital_ofdm_frame_sink */
+
+enum {
+  OFDM_OK = 0,
+  OFDM_E_INVAL = -1,     /* bad argument / configuration (std::invalid_argument in GR ctors) */
+  OFDM_E_NOMEM = -2,
+  OFDM_E_CAPACITY = -3,  /* caller-provided output buffer too small */
+  OFDM_E_HIP = -4,       /* HIP runtime error */
+  OFDM_E_OVERFLOW = -5   /* degenerate input exceeded an internal bound */
+};
+
+enum {
+  OFDM_F_DEVICE_PTRS = 1u << 0, /* bulk pointers are device pointers */
+  OFDM_F_PAD_FOR_USRP = 1u << 1 /* make_packet(pad_for_usrp=True), ofdm.py:45,144 */
+};
+
+typedef struct ofdm_c32 {
+  float re, im;
+} ofdm_c32;
+
+/*
+ * Everything ofdm_mod.__init__ / ofdm_demod.__init__ / ofdm_receiver.__init__
+ * compute before building their flow graphs (ofdm.py:63-101,204-247,
+ * ofdm_receiver.py~:69-98).  The Python host fills it; the engine copies it.
+ */
+typedef struct ofdm_cfg {
+  uint32_t struct_size; /* sizeof(ofdm_cfg), ABI guard */
+  int32_t device_id;    /* HIP device ordinal */
+  uint32_t flags;       /* OFDM_F_* */
+
+  uint32_t fft_length;     /* options.fft_length      (ofdm.py:64)  power of two, 64..4096 */
+  uint32_t occupied_tones; /* options.occupied_tones  (ofdm.py:65)  */
+  uint32_t cp_length;      /* options.cp_length       (ofdm.py:66)  */
+  uint32_t arity;          /* len(rotated_const)      (ofdm.py:91-92) */
+
+  ofdm_c32 constellation[OFDM_MAX_ARITY]; /* rotated_const (ofdm.py:98-101) */
+  ofdm_c32 known_symbol[OFDM_MAX_FFT];    /* ksfreq, occupied_tones entries (ofdm.py:73-77) */
+
+  float tx_amplitude; /* transmit_path._tx_amplitude after the [0,1] clamp (transmit_path.py:56-62) */
+
+  float phase_gain;           /* ofdm_frame_sink phase_gain 0.25 (ofdm.py:238) */
+  float freq_gain;            /* ofdm_frame_sink freq_gain  0.25*0.25/4 (ofdm.py:239) */
+  float eq_gain;              /* digital_ofdm_frame_sink d_eq_gain 0.05 */
+  uint32_t max_fft_shift_len; /* ofdm_frame_acquisition max_fft_shift_len 4 (digital_swig.py:4318-4328) */
+  uint32_t sampler_timeout;   /* ofdm_sampler timeout 1000 (digital_swig.py:4719-4724) */
+
+  float peak_rise;  /* gr_peak_detector_fb threshold_factor_rise 0.20 (ofdm_sync_pn) */
+  float peak_fall;  /* gr_peak_detector_fb threshold_factor_fall 0.20 */
+  float peak_alpha; /* gr_peak_detector_fb alpha 0.001 */
+
+  uint32_t ntaps;             /* len(chan_coeffs), odd (ofdm_receiver.py~:71-75) */
+  float taps[OFDM_MAX_TAPS];  /* gr.firdes.low_pass(1, 1, bw+tb, tb, WIN_HAMMING) as float32 */
+
+  uint8_t whitening_mask[OFDM_MASK_LEN]; /* random_mask_tuple (ofdm_packet_utils.py:195-452) */
+  uint32_t whitener_offset;              /* make_packet whitener_offset, 0..15 (ofdm_packet_utils.py:100) */
+
+  uint64_t pad_seed; /* seed of the counter-based generator that replaces the mapper's rand()%arity fill */
+} ofdm_cfg;
+
+/* Synthetic channel fused into the TX store (replaces the UHD sink/source pair
+ * usrp_transmit_path.py:66-72 / usrp_receive_path.py:67-73 for loopback). */
+typedef struct ofdm_chan {
+  float sigma;             /* AWGN: y = x + sigma*(g1 + j g2)/sqrt(2), g ~ N(0,1) */
+  float cfo;               /* carrier offset, radians per sample: x[n] *= exp(j*cfo*n) */
+  uint64_t seed;           /* Philox-4x32-10 key low */
+  uint64_t stream_id;      /* Philox-4x32-10 key high */
+  uint64_t lead_samples;   /* noise-only samples before the first packet */
+  uint64_t tail_samples;   /* noise-only samples after the last packet  */
+} ofdm_chan;
+
+/* per-call counters; the cross-GPU reduce sums these */
+typedef struct ofdm_stats {
+  uint64_t symbols;          /* OFDM symbols processed (TX: emitted incl. preambles; RX: demodulated + preambles) */
+  uint64_t samples;          /* IQ samples produced / consumed */
+  uint64_t peaks;            /* timing flags raised by the peak detector */
+  uint64_t frames;           /* preambles accepted by the sampler */
+  uint64_t headers_ok;       /* frames whose 2x16-bit header halves matched */
+  uint64_t packets;          /* messages the frame sink posted */
+  uint64_t crc_ok;           /* packets whose CRC-32 checked */
+  uint64_t chained_frames;   /* frames consumed as payload of an earlier unfinished packet */
+  uint64_t overflow;         /* non-zero: an internal bound was hit, result incomplete */
+} ofdm_stats;
+
+typedef struct ofdm_handle ofdm_handle;
+
+/* --- lifecycle ---------------------------------------------------------- */
+int ofdm_abi_version(void);
+int ofdm_device_count(void);
+/* replaces ofdm_mod.__init__/ofdm_demod.__init__ graph construction (ofdm.py:45-131,186-261) */
+int ofdm_create(const ofdm_cfg *cfg, ofdm_handle **out);
+void ofdm_destroy(ofdm_handle *h);
+const char *ofdm_last_error(const ofdm_handle *h); /* h may be NULL: error of the last failed ofdm_create */
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the handle's own stream */
+int ofdm_set_stream(ofdm_handle *h, void *hip_stream);
+/* transmit_path.set_tx_amplitude (transmit_path.py:56-62); clamps to [0,1] */
+int ofdm_set_tx_amplitude(ofdm_handle *h, float ampl);
+/* channel applied inside ofdm_tx; NULL disables it */
+int ofdm_set_channel(ofdm_handle *h, const ofdm_chan *chan);
+
+/* --- packet framing ------------------------------------------------------
+ * Batched make_packet / unmake_packet (ofdm_packet_utils.py:99-143,169-191)
+ * incl. digital_crc32 (digital_swig.py:3151-3169).  Framed packet k occupies
+ * framed[framed_off[k] .. +payload_len[k]+9 (+USRP pad)].                  */
+int ofdm_framed_len(const ofdm_handle *h, uint32_t payload_len, uint32_t *framed_len);
+int ofdm_make_packets(ofdm_handle *h, const uint8_t *payloads, const uint64_t *payload_off,
+                      const uint32_t *payload_len, int npkt, uint8_t *framed, uint64_t framed_cap,
+                      uint64_t *framed_off /* npkt+1, host, out */);
+
+/* --- transmit: ofdm_mod.send_pkt ... multiply_const (ofdm.py:106-118,133-148;
+ *     transmit_path.py:47-54) ------------------------------------------------
+ * payload bytes in -> make_packet -> ofdm_mapper_bcv -> ofdm_insert_preamble
+ * -> fft_vcc(inverse, shift) -> ofdm_cyclic_prefixer -> 1/sqrt(N) -> amp
+ * [-> channel].  Packet k starts at sample lead + sym_off[k]*(N+CP).         */
+int ofdm_tx_frame_count(const ofdm_handle *h, const uint32_t *payload_len, int npkt,
+                        uint64_t *nsymbols, uint64_t *nsamples /* incl. channel lead/tail */);
+int ofdm_tx(ofdm_handle *h, const uint8_t *payloads, const uint64_t *payload_off,
+            const uint32_t *payload_len, int npkt, ofdm_c32 *iq_out, uint64_t iq_cap,
+            uint64_t *nsamples, ofdm_stats *stats /* may be NULL */);
+
+/* standalone channel on an existing IQ buffer (same generator as the fused one;
+ * sample n of the buffer is stream sample index0+n) */
+int ofdm_channel(ofdm_handle *h, ofdm_c32 *iq, uint64_t n, const ofdm_chan *chan, uint64_t index0);
+
+/* --- receive: ofdm_demod (ofdm.py:221-261) = ofdm_receiver (ofdm_receiver.py~:131-142)
+ *     + ofdm_frame_sink + _queue_watcher_thread/unmake_packet (ofdm.py:300-305) ---
+ * One contiguous IQ stream in; for every message the frame sink would post,
+ * in stream order: payload bytes (CRC stripped), length, CRC verdict.  These
+ * are exactly the (ok, payload) pairs the reference hands to its callback.  */
+int ofdm_rx(ofdm_handle *h, const ofdm_c32 *iq, uint64_t nsamples, uint8_t *payload_out,
+            uint64_t payload_cap, uint64_t *payload_off /* max_pkts+1, host */,
+            uint32_t *payload_len /* max_pkts, host */, uint8_t *crc_ok /* max_pkts, host */,
+            int max_pkts, int *npkt, ofdm_stats *stats /* may be NULL */);
+
+/* --- debug taps: the reference's --log probe points (ofdm.py:123-131,253-254;
+ *     ofdm_receiver.py~:144-152).  Enable before the call, read after.  Output
+ *     is always copied to HOST memory. ---------------------------------------- */
+enum {
+  OFDM_TAP_TX_PACKETS = 0,   /* uint8: framed packets, concatenated                               */
+  OFDM_TAP_TX_FREQ = 1,      /* c32[nsym][N]: ofdm_preambles.dat (mapper+preamble output)        */
+  OFDM_TAP_RX_CHAN_FILT = 2, /* c32[nsamples]: ofdm_receiver-chan_filt_c.dat                      */
+  OFDM_TAP_RX_METRIC = 3,    /* f32[nsamples]: peak-detector input (M-bar - 1)                    */
+  OFDM_TAP_RX_PEAKS = 4,     /* u64[npeaks]: timing-flag sample indices                           */
+  OFDM_TAP_RX_ANGLES = 5,    /* f32[npeaks]: sample-and-held angle(P) at each flag                */
+  OFDM_TAP_RX_FRAMES = 6,    /* u64[nframes][2]: (flag index, data symbols emitted) per sampler frame */
+  OFDM_TAP_RX_FFT = 7,       /* c32[nsym][N]: ofdm_receiver-fft_out_c.dat                         */
+  OFDM_TAP_RX_ACQ = 8,       /* c32[nsym][occ]: ofdm_receiver-frame_acq_c.dat                     */
+  OFDM_TAP_RX_SINK = 9,      /* c32[ndemapped][occ]: ofdm_frame_sink_c.dat (derotated carriers)   */
+  OFDM_TAP_RX_PACKETS = 10,  /* uint8: frame-sink messages before dewhitening, concatenated      */
+  OFDM_TAP_COUNT = 11
+};
+int ofdm_set_taps(ofdm_handle *h, uint32_t tap_mask); /* bit i enables OFDM_TAP_i */
+int ofdm_tap(ofdm_handle *h, int tap, void *out_host, uint64_t cap_bytes, uint64_t *nbytes);
+
+/* --- measurement: per-kernel HIP-event timing on the handle's stream -------- */
+enum {
+  OFDM_K_FRAME = 0, /* make_packet: CRC-32 + header + whitening              */
+  OFDM_K_TX = 1,    /* map + preamble + IFFT + CP + scale (+channel)         */
+  OFDM_K_CHAN = 2,  /* standalone channel                                    */
+  OFDM_K_SYNC = 3,  /* channel filter + Schmidl-Cox metric + candidates      */
+  OFDM_K_PEAK = 4,  /* peak detector / sampler / NCO bookkeeping             */
+  OFDM_K_DEMOD = 5, /* derotate + FFT + frame acquisition + frame sink       */
+  OFDM_K_DEFRAME = 6, /* dewhiten + CRC check + output compaction            */
+  OFDM_K_COUNT = 7
+};
+int ofdm_prof_enable(ofdm_handle *h, int on);
+int ofdm_prof_reset(ofdm_handle *h);
+int ofdm_prof_get(ofdm_handle *h, int kernel, double *total_ms, uint64_t *launches);
+const char *ofdm_kernel_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFDM_HIP_H */

@@ -1,0 +1,156 @@
+// common.h -- device helpers shared by the OFDM kernels (gfx950 only).
+//
+// Arithmetic rule of this code base: the translation unit is compiled with
+// -ffp-contract=off, so `a*b + c` is two roundings exactly like the GNU Radio
+// blocks it restates; every fused multiply-add is an explicit fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ofdm_hip.h"
+
+#define WAVE 64
+
+struct c32 {
+  float re, im;
+};
+static_assert(sizeof(c32) == 8, "c32 must be an interleaved float pair");
+
+__device__ __forceinline__ c32 mk(float re, float im) {
+  c32 z;
+  z.re = re;
+  z.im = im;
+  return z;
+}
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return mk(a.re - b.re, a.im - b.im); }
+// gr_complex product: two products and one add per part, separately rounded
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) {
+  return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+__device__ __forceinline__ c32 cmul_conj(c32 a, c32 b) {  // a * conj(b)
+  return mk(a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im);
+}
+__device__ __forceinline__ c32 cdiv(c32 a, c32 b) {
+  float den = b.re * b.re + b.im * b.im;
+  return mk((a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den);
+}
+__device__ __forceinline__ float cnorm(c32 a) { return a.re * a.re + a.im * a.im; }
+// fused complex multiply for the FFT butterflies (tolerance-level arithmetic)
+__device__ __forceinline__ c32 cmul_f(c32 a, c32 b) {
+  return mk(fmaf(a.re, b.re, -(a.im * b.im)), fmaf(a.re, b.im, a.im * b.re));
+}
+
+// ---- wave / block scans -------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan_add(T v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    T o = __shfl_up(v, d, WAVE);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
+}
+
+// Exclusive block scan (sum).  `scratch` holds one T per wave (+1).  All threads
+// of the block must call it; contains two __syncthreads().  Returns the exclusive
+// prefix of `v`; *total receives the block total.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_add(T v, T* scratch, T* total) {
+  const int lane = lane_id(), w = wave_id();
+  const int nw = (blockDim.x + WAVE - 1) / WAVE;
+  T inc = wave_incl_scan_add(v);
+  if (lane == WAVE - 1) scratch[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+  for (int i = 0; i < nw; i++) {
+    T s = scratch[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// ---- Q23.40 fixed point for the order-independent moving sums -----------------
+#define Q40_SCALE 1099511627776.0          /* 2^40 */
+#define Q40_INV (1.0 / 1099511627776.0)    /* 2^-40 */
+
+// llrint(v * 2^40) for |v| <= 1024, bit-identical to the CPU's llrint: adding
+// 1.5*2^52 makes the FPU do the round-to-nearest-even to an integer, whose value
+// then sits in the low mantissa bits.
+__device__ __forceinline__ long long q40_from_float(float v) {
+  double t = (double)v * Q40_SCALE + 6755399441055744.0;  // 1.5 * 2^52
+  long long b = __double_as_longlong(t);
+  return (b & 0x000FFFFFFFFFFFFFll) - 0x0008000000000000ll;
+}
+__device__ __forceinline__ long long q40_clamped(float v) {
+  v = fminf(fmaxf(v, -511.0f), 511.0f);
+  return q40_from_float(v);
+}
+__device__ __forceinline__ double q40_to_double(long long s) { return (double)s * Q40_INV; }
+
+// ---- misc -----------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t pad_symbol_hash(uint64_t seed, uint64_t pkt, uint64_t slot,
+                                                             uint32_t arity) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (pkt + 1) + 0xBF58476D1CE4E5B9ull * (slot + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)((z >> 32) % arity);
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0;
+    uint32_t n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0;
+    c[1] = lo1;
+    c[2] = n2;
+    c[3] = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// one channel use: rotate by the carrier offset and add circular Gaussian noise
+__device__ __forceinline__ c32 channel_apply(c32 x, uint64_t idx, float sigma, float cfo, uint64_t seed,
+                                             uint64_t stream) {
+  if (cfo != 0.0f) {
+    double ph = (double)cfo * (double)idx;
+    ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
+    double s, c;
+    sincos(ph, &s, &c);
+    x = cmul(x, mk((float)c, (float)s));
+  }
+  if (sigma > 0.0f) {
+    uint32_t ctr[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float inv24 = 1.0f / 16777216.0f;
+    float u1 = ((float)(ctr[0] >> 8) + 0.5f) * inv24;
+    float u2 = ((float)(ctr[1] >> 8) + 0.5f) * inv24;
+    float rad = sqrtf(-2.0f * logf(u1));
+    float th = 6.28318530717958647692f * u2;
+    float sn, cs;
+    sincosf(th, &sn, &cs);
+    float s = sigma * 0.70710678118654752440f;
+    x.re = x.re + s * (rad * cs);
+    x.im = x.im + s * (rad * sn);
+  }
+  return x;
+}

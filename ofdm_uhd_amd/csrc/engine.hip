@@ -1,0 +1,586 @@
+// engine.hip -- libofdm_hip.so: handle, workspaces and the C ABI of include/ofdm_hip.h.
+// gfx950 (MI355X) only.  Build: see Makefile (hipcc --offload-arch=gfx950 -ffp-contract=off).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "fft.h"
+#include "host_util.h"
+#include "tx.h"
+#include "rx_sync.h"
+#include "rx_demod.h"
+
+static std::string g_create_error;
+
+#define HIPCHK(h, expr)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+      return OFDM_E_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define FAIL(h, code, msg) \
+  do {                     \
+    (h)->err = (msg);      \
+    return (code);         \
+  } while (0)
+
+struct ofdm_handle {
+  ofdm_cfg cfg;
+  int N = 0, CP = 0, L = 0, occ = 0, nbits = 0, zl = 0;
+  int nc = 0;    // data carriers of the mapper (map into the N bins)
+  int nmap = 0;  // data carriers of the frame sink (map into the occupied block)
+  bool dev_ptrs = false;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+
+  // constant tables
+  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_taps, d_ks, d_smap, d_kd;
+
+  // TX workspaces
+  DevBuf d_payloads, d_payload_off, d_payload_len, d_framed, d_framed_off, d_sym_off, d_sym_pkt, d_iq_stage,
+      d_freq_tap;
+  PinBuf h_meta;
+  std::vector<uint64_t> framed_off, sym_off;
+  uint64_t last_tx_nsym = 0, last_tx_framed_bytes = 0;
+  int last_tx_npkt = 0;
+
+  // channel
+  bool chan_on = false;
+  ofdm_chan chan;
+
+  uint32_t tap_mask = 0;
+  Profiler prof;
+
+  RxState rx;  // receive-side workspaces (rx_demod.h)
+};
+
+// ------------------------------------------------------------------------------
+static int ilog2_ceil(unsigned v) {
+  int n = 0;
+  while ((1u << n) < v) n++;
+  return n;
+}
+
+// digital_ofdm_mapper_bcv / digital_ofdm_frame_sink carrier map from the default "FE7F"
+// string (transmit_path.py:64; reset_carrier_map is commented out at :67)
+static int build_carrier_map(int occ, int container, std::vector<int>& map) {
+  std::vector<int> digits;
+  if (occ < 16) return OFDM_E_INVAL;
+  int diff = occ - 16, nf = 0;
+  while (diff > 7) {
+    nf++;
+    diff -= 8;
+  }
+  int dl = 0, dr = 0;
+  if (diff > 0) {
+    dl = (diff + 1) / 2;
+    dr = diff - dl;
+    digits.push_back((1 << dl) - 1);
+  }
+  for (int i = 0; i < nf; i++) digits.push_back(0xF);
+  digits.push_back(0xF);
+  digits.push_back(0xE);
+  digits.push_back(0x7);
+  digits.push_back(0xF);
+  for (int i = 0; i < nf; i++) digits.push_back(0xF);
+  if (diff > 0) digits.push_back(0xF ^ ((1 << dr) - 1));
+  int pad = (container / 4 - (int)digits.size()) / 2;
+  map.clear();
+  for (size_t i = 0; i < digits.size(); i++)
+    for (int j = 0; j < 4; j++)
+      if ((digits[i] >> (3 - j)) & 1) {
+        int idx = 4 * ((int)i + pad) + j;
+        if (idx < 0 || idx >= container) return OFDM_E_INVAL;
+        map.push_back(idx);
+      }
+  if ((int)map.size() > occ) return OFDM_E_INVAL;
+  return OFDM_OK;
+}
+
+template <typename T>
+static hipError_t upload(DevBuf& b, const T* src, size_t count) {
+  hipError_t e = b.ensure(sizeof(T) * std::max<size_t>(count, 1));
+  if (e != hipSuccess) return e;
+  if (count) return hipMemcpy(b.p, src, sizeof(T) * count, hipMemcpyHostToDevice);
+  return hipSuccess;
+}
+
+static uint32_t npadding_bytes(uint32_t pkt_byte_len) {
+  // _npadding_bytes(len, samples_per_symbol=1, bits_per_symbol=1) as ofdm.py:144 calls it
+  uint32_t r = pkt_byte_len % 16u;
+  return r == 0 ? 0 : 16u - r;
+}
+
+static int framed_len_of(const ofdm_cfg& cfg, uint32_t payload_len, uint32_t* out) {
+  uint32_t Lp = payload_len + 4;
+  if (Lp > OFDM_MASK_LEN) return OFDM_E_INVAL;  // "len(payload) must be in [0, 4096]" (ofdm_packet_utils.py:123-126)
+  uint32_t n = 4 + Lp + 1;
+  if (cfg.flags & OFDM_F_PAD_FOR_USRP) n += npadding_bytes(n);
+  if (cfg.whitener_offset + (n - 4) > OFDM_MASK_LEN) return OFDM_E_INVAL;  // whitening mask exhausted
+  *out = n;
+  return OFDM_OK;
+}
+
+static TxParams make_tx_params(const ofdm_handle* h) {
+  TxParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = h->N;
+  p.CP = h->CP;
+  p.L = h->L;
+  p.occ = h->occ;
+  p.nc = h->nc;
+  p.nbits = h->nbits;
+  p.arity = (int)h->cfg.arity;
+  p.zl = h->zl;
+  p.scale1 = (float)(1.0 / sqrt((double)h->N));
+  p.amp = h->cfg.tx_amplitude;
+  p.pad_seed = h->cfg.pad_seed;
+  p.whitener_offset = h->cfg.whitener_offset;
+  p.pad_for_usrp = (h->cfg.flags & OFDM_F_PAD_FOR_USRP) ? 1u : 0u;
+  p.constellation = h->d_const.as<c32>();
+  p.preamble = h->d_preamble.as<c32>();
+  p.bin2car = h->d_bin2car.as<int16_t>();
+  p.tw = h->d_tw.as<c32>();
+  p.mask = h->d_mask.as<uint8_t>();
+  p.crc_table = h->d_crc.as<uint32_t>();
+  p.chan_on = h->chan_on ? 1 : 0;
+  p.sigma = h->chan.sigma;
+  p.cfo = h->chan.cfo;
+  p.seed = h->chan.seed;
+  p.stream = h->chan.stream_id;
+  return p;
+}
+
+// ------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------
+extern "C" int ofdm_abi_version(void) { return OFDM_ABI_VERSION; }
+
+extern "C" int ofdm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char* ofdm_last_error(const ofdm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" const char* ofdm_kernel_name(int k) {
+  static const char* names[OFDM_K_COUNT] = {"k_frame_pack", "k_tx_mod",   "k_channel", "k_sync",
+                                            "k_peak",       "k_rx_demod", "k_deframe"};
+  return (k >= 0 && k < OFDM_K_COUNT) ? names[k] : "?";
+}
+
+static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
+  h->cfg = *cfg;
+  const int N = (int)cfg->fft_length, occ = (int)cfg->occupied_tones, CP = (int)cfg->cp_length;
+  if (N < 64 || N > OFDM_MAX_FFT || (N & (N - 1))) FAIL(h, OFDM_E_INVAL, "fft_length must be a power of two in [64, 4096]");
+  if (occ > N) FAIL(h, OFDM_E_INVAL, "occupied_tones > fft_length (digital_ofdm_mapper_bcv ctor)");
+  if (occ < 16) FAIL(h, OFDM_E_INVAL, "occupied_tones < 16");
+  if (CP < 1 || CP > N) FAIL(h, OFDM_E_INVAL, "cp_length must be in [1, fft_length]");
+  if (cfg->arity < 2 || cfg->arity > OFDM_MAX_ARITY) FAIL(h, OFDM_E_INVAL, "arity must be in [2, 256]");
+  if (cfg->ntaps < 1 || cfg->ntaps > OFDM_MAX_TAPS) FAIL(h, OFDM_E_INVAL, "ntaps must be in [1, 512]");
+  if (cfg->whitener_offset > 15) FAIL(h, OFDM_E_INVAL, "whitener_offset must be between 0 and 15, inclusive");
+  if (!(cfg->peak_rise > 0.f) || !(cfg->peak_fall > 0.f) || !(cfg->peak_alpha > 0.f) || !(cfg->peak_alpha < 1.f))
+    FAIL(h, OFDM_E_INVAL, "peak detector factors must be positive, alpha in (0,1)");
+  if (cfg->max_fft_shift_len > 64) FAIL(h, OFDM_E_INVAL, "max_fft_shift_len too large");
+  h->N = N;
+  h->CP = CP;
+  h->L = N + CP;
+  h->occ = occ;
+  h->nbits = ilog2_ceil(cfg->arity);
+  h->zl = (N - occ + 1) / 2;  // ceil((N-occ)/2), ofdm.py:71
+  h->dev_ptrs = (cfg->flags & OFDM_F_DEVICE_PTRS) != 0;
+
+  int ndev = 0;
+  HIPCHK(h, hipGetDeviceCount(&ndev));
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) FAIL(h, OFDM_E_INVAL, "device_id out of range");
+  HIPCHK(h, hipSetDevice(cfg->device_id));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+
+  std::vector<int> cmap, smap;
+  if (build_carrier_map(occ, N, cmap) != OFDM_OK) FAIL(h, OFDM_E_INVAL, "cannot build the mapper's subcarrier map");
+  if (build_carrier_map(occ, occ, smap) != OFDM_OK) FAIL(h, OFDM_E_INVAL, "cannot build the frame sink's subcarrier map");
+  h->nc = (int)cmap.size();
+  h->nmap = (int)smap.size();
+
+  // tables
+  std::vector<int16_t> bin2car(N, (int16_t)-1);
+  for (int i = 0; i < h->nc; i++) bin2car[cmap[i]] = (int16_t)i;
+  std::vector<c32> pre(N), tw(N);
+  for (int i = 0; i < N; i++) pre[i] = c32{0.f, 0.f};
+  for (int i = 0; i < occ; i++) {
+    if (h->zl + i < N) pre[h->zl + i] = c32{cfg->known_symbol[i].re, cfg->known_symbol[i].im};
+  }
+  for (int k = 0; k < N; k++) {
+    double a = -2.0 * M_PI * (double)k / (double)N;
+    tw[k] = c32{(float)cos(a), (float)sin(a)};
+  }
+  uint32_t crc[256];
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    crc[i] = c;
+  }
+  // taps padded with zeros to a multiple of 8 (fmaf(0, x, acc) == acc)
+  std::vector<float> taps((cfg->ntaps + 7) / 8 * 8 + 8, 0.0f);
+  for (uint32_t i = 0; i < cfg->ntaps; i++) taps[i] = cfg->taps[i];
+  // known_phase_diff of digital_ofdm_frame_acquisition's ctor
+  std::vector<float> kd(occ, 0.0f);
+  for (int i = 0; i + 2 < occ; i += 2) {
+    float dr = cfg->known_symbol[i].re - cfg->known_symbol[i + 2].re;
+    float di = cfg->known_symbol[i].im - cfg->known_symbol[i + 2].im;
+    kd[i] = dr * dr + di * di;
+  }
+  std::vector<int16_t> smap16(smap.begin(), smap.end());
+
+  HIPCHK(h, upload(h->d_const, reinterpret_cast<const c32*>(cfg->constellation), cfg->arity));
+  HIPCHK(h, upload(h->d_preamble, pre.data(), pre.size()));
+  HIPCHK(h, upload(h->d_tw, tw.data(), tw.size()));
+  HIPCHK(h, upload(h->d_bin2car, bin2car.data(), bin2car.size()));
+  HIPCHK(h, upload(h->d_mask, cfg->whitening_mask, (size_t)OFDM_MASK_LEN));
+  HIPCHK(h, upload(h->d_crc, crc, (size_t)256));
+  HIPCHK(h, upload(h->d_taps, taps.data(), taps.size()));
+  HIPCHK(h, upload(h->d_ks, reinterpret_cast<const c32*>(cfg->known_symbol), (size_t)occ));
+  HIPCHK(h, upload(h->d_smap, smap16.data(), smap16.size()));
+  HIPCHK(h, upload(h->d_kd, kd.data(), kd.size()));
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_create(const ofdm_cfg* cfg, ofdm_handle** out) {
+  if (!cfg || !out) {
+    g_create_error = "null argument";
+    return OFDM_E_INVAL;
+  }
+  if (cfg->struct_size != sizeof(ofdm_cfg)) {
+    g_create_error = "ofdm_cfg.struct_size does not match this library (ABI mismatch)";
+    return OFDM_E_INVAL;
+  }
+  ofdm_handle* h = new (std::nothrow) ofdm_handle();
+  if (!h) {
+    g_create_error = "out of memory";
+    return OFDM_E_NOMEM;
+  }
+  int rc = create_impl(cfg, h);
+  if (rc != OFDM_OK) {
+    g_create_error = h->err;
+    ofdm_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return OFDM_OK;
+}
+
+extern "C" void ofdm_destroy(ofdm_handle* h) {
+  if (!h) return;
+  if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  DevBuf* bufs[] = {&h->d_const,    &h->d_preamble,    &h->d_tw,          &h->d_bin2car, &h->d_mask,
+                    &h->d_crc,      &h->d_taps,        &h->d_ks,          &h->d_smap,    &h->d_kd,
+                    &h->d_payloads, &h->d_payload_off, &h->d_payload_len, &h->d_framed,  &h->d_framed_off,
+                    &h->d_sym_off,  &h->d_sym_pkt,     &h->d_iq_stage,    &h->d_freq_tap};
+  for (DevBuf* b : bufs) b->release();
+  h->h_meta.release();
+  h->rx.release();
+  h->prof.destroy();
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+extern "C" int ofdm_set_stream(ofdm_handle* h, void* s) {
+  if (!h) return OFDM_E_INVAL;
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_set_tx_amplitude(ofdm_handle* h, float ampl) {
+  if (!h) return OFDM_E_INVAL;
+  h->cfg.tx_amplitude = fmaxf(0.0f, fminf(ampl, 1.0f));  // transmit_path.py:56-62
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_set_channel(ofdm_handle* h, const ofdm_chan* c) {
+  if (!h) return OFDM_E_INVAL;
+  if (c) {
+    h->chan = *c;
+    h->chan_on = true;
+  } else {
+    memset(&h->chan, 0, sizeof(h->chan));
+    h->chan_on = false;
+  }
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_set_taps(ofdm_handle* h, uint32_t mask) {
+  if (!h) return OFDM_E_INVAL;
+  h->tap_mask = mask;
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_prof_enable(ofdm_handle* h, int on) {
+  if (!h) return OFDM_E_INVAL;
+  h->prof.on = on != 0;
+  return OFDM_OK;
+}
+extern "C" int ofdm_prof_reset(ofdm_handle* h) {
+  if (!h) return OFDM_E_INVAL;
+  h->prof.reset();
+  return OFDM_OK;
+}
+extern "C" int ofdm_prof_get(ofdm_handle* h, int k, double* total_ms, uint64_t* launches) {
+  if (!h || k < 0 || k >= OFDM_K_COUNT) return OFDM_E_INVAL;
+  if (total_ms) *total_ms = h->prof.total_ms[k];
+  if (launches) *launches = h->prof.launches[k];
+  return OFDM_OK;
+}
+
+// ------------------------------------------------------------------------------
+// framing + TX
+// ------------------------------------------------------------------------------
+extern "C" int ofdm_framed_len(const ofdm_handle* h, uint32_t payload_len, uint32_t* framed_len) {
+  if (!h || !framed_len) return OFDM_E_INVAL;
+  return framed_len_of(h->cfg, payload_len, framed_len);
+}
+
+// layout of a batch: framed byte offsets and symbol offsets (host)
+static int plan_batch(ofdm_handle* h, const uint32_t* payload_len, int npkt, bool* uniform, uint32_t* spp) {
+  h->framed_off.assign((size_t)npkt + 1, 0);
+  h->sym_off.assign((size_t)npkt + 1, 0);
+  const uint64_t per = (uint64_t)h->nc * (uint64_t)h->nbits;
+  bool uni = true;
+  uint32_t first = 0;
+  for (int k = 0; k < npkt; k++) {
+    uint32_t fl;
+    int rc = framed_len_of(h->cfg, payload_len[k], &fl);
+    if (rc) FAIL(h, rc, "len(payload) must be in [0, 4091] (payload + CRC must fit the 12-bit length and the whitening mask)");
+    h->framed_off[k + 1] = h->framed_off[k] + fl;
+    // a symbol is started while message bytes remain: ceil(8*len / (carriers*nbits)), plus the preamble
+    uint32_t ns = (uint32_t)((8ull * fl + per - 1) / per) + 1;
+    h->sym_off[k + 1] = h->sym_off[k] + ns;
+    if (k == 0)
+      first = ns;
+    else if (ns != first)
+      uni = false;
+  }
+  *uniform = uni && npkt > 0;
+  *spp = first;
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_tx_frame_count(const ofdm_handle* hc, const uint32_t* payload_len, int npkt, uint64_t* nsymbols,
+                                   uint64_t* nsamples) {
+  ofdm_handle* h = const_cast<ofdm_handle*>(hc);
+  if (!h || npkt < 0 || (npkt && !payload_len)) return OFDM_E_INVAL;
+  bool uni;
+  uint32_t spp;
+  int rc = plan_batch(h, payload_len, npkt, &uni, &spp);
+  if (rc) return rc;
+  uint64_t ns = h->sym_off[npkt];
+  if (nsymbols) *nsymbols = ns;
+  if (nsamples) *nsamples = ns * (uint64_t)h->L + (h->chan_on ? h->chan.lead_samples + h->chan.tail_samples : 0);
+  return OFDM_OK;
+}
+
+// uploads the batch metadata and (in host-pointer mode) the payload bytes
+static int stage_batch(ofdm_handle* h, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* payload_len,
+                       int npkt, const uint8_t** d_payloads) {
+  const size_t n1 = (size_t)npkt + 1;
+  // pinned staging: payload_off[npkt] | framed_off[n1] | sym_off[n1] | payload_len[npkt]
+  size_t bytes = sizeof(uint64_t) * (npkt + 2 * n1) + sizeof(uint32_t) * npkt;
+  HIPCHK(h, h->h_meta.ensure(bytes));
+  uint64_t* m_poff = h->h_meta.as<uint64_t>();
+  uint64_t* m_foff = m_poff + npkt;
+  uint64_t* m_soff = m_foff + n1;
+  uint32_t* m_plen = reinterpret_cast<uint32_t*>(m_soff + n1);
+  memcpy(m_poff, payload_off, sizeof(uint64_t) * npkt);
+  memcpy(m_foff, h->framed_off.data(), sizeof(uint64_t) * n1);
+  memcpy(m_soff, h->sym_off.data(), sizeof(uint64_t) * n1);
+  memcpy(m_plen, payload_len, sizeof(uint32_t) * npkt);
+  HIPCHK(h, h->d_payload_off.ensure(sizeof(uint64_t) * n1));
+  HIPCHK(h, h->d_framed_off.ensure(sizeof(uint64_t) * n1));
+  HIPCHK(h, h->d_sym_off.ensure(sizeof(uint64_t) * n1));
+  HIPCHK(h, h->d_payload_len.ensure(sizeof(uint32_t) * n1));
+  HIPCHK(h, hipMemcpyAsync(h->d_payload_off.p, m_poff, sizeof(uint64_t) * npkt, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_framed_off.p, m_foff, sizeof(uint64_t) * n1, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_sym_off.p, m_soff, sizeof(uint64_t) * n1, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_payload_len.p, m_plen, sizeof(uint32_t) * npkt, hipMemcpyHostToDevice, h->stream));
+  if (h->dev_ptrs) {
+    *d_payloads = payloads;
+  } else {
+    uint64_t total = 0;
+    for (int k = 0; k < npkt; k++) total = std::max<uint64_t>(total, payload_off[k] + payload_len[k]);
+    HIPCHK(h, h->d_payloads.ensure(std::max<uint64_t>(total, 1)));
+    if (total) HIPCHK(h, hipMemcpyAsync(h->d_payloads.p, payloads, total, hipMemcpyHostToDevice, h->stream));
+    *d_payloads = h->d_payloads.as<uint8_t>();
+  }
+  return OFDM_OK;
+}
+
+static int launch_frame_pack(ofdm_handle* h, const uint8_t* d_payloads, int npkt, uint8_t* d_framed) {
+  TxParams p = make_tx_params(h);
+  h->prof.begin(OFDM_K_FRAME, h->stream);
+  hipLaunchKernelGGL(k_frame_pack, dim3((npkt + 255) / 256), dim3(256), 0, h->stream, p, d_payloads,
+                     h->d_payload_off.as<uint64_t>(), h->d_payload_len.as<uint32_t>(), h->d_framed_off.as<uint64_t>(),
+                     npkt, d_framed);
+  h->prof.end(h->stream);
+  HIPCHK(h, hipGetLastError());
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_make_packets(ofdm_handle* h, const uint8_t* payloads, const uint64_t* payload_off,
+                                 const uint32_t* payload_len, int npkt, uint8_t* framed, uint64_t framed_cap,
+                                 uint64_t* framed_off) {
+  if (!h) return OFDM_E_INVAL;
+  if (npkt < 0 || (npkt && (!payloads || !payload_off || !payload_len)) || !framed_off) FAIL(h, OFDM_E_INVAL, "null argument");
+  bool uni;
+  uint32_t spp;
+  int rc = plan_batch(h, payload_len, npkt, &uni, &spp);
+  if (rc) return rc;
+  memcpy(framed_off, h->framed_off.data(), sizeof(uint64_t) * ((size_t)npkt + 1));
+  const uint64_t total = h->framed_off[npkt];
+  if (total > framed_cap) FAIL(h, OFDM_E_CAPACITY, "framed buffer too small");
+  if (npkt == 0) return OFDM_OK;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const uint8_t* d_payloads = nullptr;
+  rc = stage_batch(h, payloads, payload_off, payload_len, npkt, &d_payloads);
+  if (rc) return rc;
+  uint8_t* d_framed = framed;
+  if (!h->dev_ptrs) {
+    HIPCHK(h, h->d_framed.ensure(total));
+    d_framed = h->d_framed.as<uint8_t>();
+  }
+  rc = launch_frame_pack(h, d_payloads, npkt, d_framed);
+  if (rc) return rc;
+  if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(framed, d_framed, total, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->prof.collect();
+  return OFDM_OK;
+}
+
+template <int N>
+static void launch_tx_mod(ofdm_handle* h, const TxParams& p, const uint8_t* d_framed, uint32_t uniform_spp, uint64_t nsym,
+                          uint64_t lead, c32* d_out, c32* d_freq_tap) {
+  constexpr int SPW = TxGeom<N>::SPW, WG = TxGeom<N>::WG;
+  const size_t shmem = (size_t)SPW * fft_lds_bytes(N);
+  const unsigned grid = (unsigned)((nsym + SPW - 1) / SPW);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N>), dim3(grid), dim3(WG), shmem, h->stream, p, d_framed,
+                     h->d_framed_off.as<uint64_t>(), h->d_sym_off.as<uint64_t>(), h->d_sym_pkt.as<uint32_t>(),
+                     uniform_spp, nsym, lead, d_out, d_freq_tap);
+}
+
+static int launch_noise(ofdm_handle* h, c32* d_iq, uint64_t n, uint64_t index0, int zero_input, const ofdm_chan& ch) {
+  if (n == 0) return OFDM_OK;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 8);
+  h->prof.begin(OFDM_K_CHAN, h->stream);
+  hipLaunchKernelGGL(k_channel, dim3(grid), dim3(256), 0, h->stream, d_iq, n, index0, zero_input, ch.sigma, ch.cfo,
+                     ch.seed, ch.stream_id);
+  h->prof.end(h->stream);
+  HIPCHK(h, hipGetLastError());
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_tx(ofdm_handle* h, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* payload_len,
+                       int npkt, ofdm_c32* iq_out, uint64_t iq_cap, uint64_t* nsamples, ofdm_stats* stats) {
+  if (!h) return OFDM_E_INVAL;
+  if (npkt < 0 || (npkt && (!payloads || !payload_off || !payload_len)) || !nsamples) FAIL(h, OFDM_E_INVAL, "null argument");
+  bool uni;
+  uint32_t spp;
+  int rc = plan_batch(h, payload_len, npkt, &uni, &spp);
+  if (rc) return rc;
+  const uint64_t nsym = h->sym_off[npkt];
+  const uint64_t lead = h->chan_on ? h->chan.lead_samples : 0, tail = h->chan_on ? h->chan.tail_samples : 0;
+  const uint64_t total = lead + nsym * (uint64_t)h->L + tail;
+  *nsamples = total;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->symbols = nsym;
+    stats->samples = total;
+    stats->packets = (uint64_t)npkt;
+  }
+  if (total > iq_cap) FAIL(h, OFDM_E_CAPACITY, "iq_out too small (see ofdm_tx_frame_count)");
+  if (total == 0) return OFDM_OK;
+  if (!iq_out) FAIL(h, OFDM_E_INVAL, "null iq_out");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+
+  c32* d_out = reinterpret_cast<c32*>(iq_out);
+  if (!h->dev_ptrs) {
+    HIPCHK(h, h->d_iq_stage.ensure(total * sizeof(c32)));
+    d_out = h->d_iq_stage.as<c32>();
+  }
+  if (npkt > 0) {
+    const uint8_t* d_payloads = nullptr;
+    rc = stage_batch(h, payloads, payload_off, payload_len, npkt, &d_payloads);
+    if (rc) return rc;
+    HIPCHK(h, h->d_framed.ensure(h->framed_off[npkt]));
+    rc = launch_frame_pack(h, d_payloads, npkt, h->d_framed.as<uint8_t>());
+    if (rc) return rc;
+    HIPCHK(h, h->d_sym_pkt.ensure(sizeof(uint32_t) * std::max<uint64_t>(nsym, 1)));
+    if (!uni) {
+      hipLaunchKernelGGL(k_sym_desc, dim3((npkt + 255) / 256), dim3(256), 0, h->stream, h->d_sym_off.as<uint64_t>(), npkt,
+                         h->d_sym_pkt.as<uint32_t>());
+      HIPCHK(h, hipGetLastError());
+    }
+    c32* d_freq = nullptr;
+    if (h->tap_mask & (1u << OFDM_TAP_TX_FREQ)) {
+      HIPCHK(h, h->d_freq_tap.ensure(nsym * (uint64_t)h->N * sizeof(c32)));
+      d_freq = h->d_freq_tap.as<c32>();
+    }
+    TxParams p = make_tx_params(h);
+    const uint32_t uspp = uni ? spp : 0;
+    h->prof.begin(OFDM_K_TX, h->stream);
+    switch (h->N) {
+      case 64: launch_tx_mod<64>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+      case 128: launch_tx_mod<128>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+      case 256: launch_tx_mod<256>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+      case 512: launch_tx_mod<512>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+      case 1024: launch_tx_mod<1024>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+      case 2048: launch_tx_mod<2048>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+      default: launch_tx_mod<4096>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+    }
+    h->prof.end(h->stream);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->last_tx_nsym = nsym;
+  h->last_tx_npkt = npkt;
+  h->last_tx_framed_bytes = npkt ? h->framed_off[npkt] : 0;
+  // noise-only lead-in and tail (the modulator covers everything in between)
+  if (h->chan_on) {
+    rc = launch_noise(h, d_out, lead, 0, 1, h->chan);
+    if (rc) return rc;
+    rc = launch_noise(h, d_out + lead + nsym * (uint64_t)h->L, tail, lead + nsym * (uint64_t)h->L, 1, h->chan);
+    if (rc) return rc;
+  }
+  if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(iq_out, d_out, total * sizeof(c32), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->prof.collect();
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_channel(ofdm_handle* h, ofdm_c32* iq, uint64_t n, const ofdm_chan* chan, uint64_t index0) {
+  if (!h) return OFDM_E_INVAL;
+  if (!chan || (n && !iq)) FAIL(h, OFDM_E_INVAL, "null argument");
+  if (n == 0) return OFDM_OK;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  c32* d = reinterpret_cast<c32*>(iq);
+  if (!h->dev_ptrs) {
+    HIPCHK(h, h->d_iq_stage.ensure(n * sizeof(c32)));
+    d = h->d_iq_stage.as<c32>();
+    HIPCHK(h, hipMemcpyAsync(d, iq, n * sizeof(c32), hipMemcpyHostToDevice, h->stream));
+  }
+  int rc = launch_noise(h, d, n, index0, 0, *chan);
+  if (rc) return rc;
+  if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(iq, d, n * sizeof(c32), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->prof.collect();
+  return OFDM_OK;
+}
+
+#include "engine_rx.inc"

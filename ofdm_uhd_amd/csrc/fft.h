@@ -1,0 +1,185 @@
+// fft.h -- batched small-N FFT/IFFT staged in LDS (replaces gr.fft_vcc over FFTW,
+// ofdm.py:112 / ofdm_receiver.py~:126).
+//
+// One transform of length N is done by N/8 threads that each hold 8 points in
+// registers: Stockham autosort passes of radix 8 (plus one leading radix-2 or
+// radix-4 pass when N is not a power of 8).  The first pass takes its inputs
+// from registers and the last leaves its outputs in registers, so a 512-point
+// transform crosses LDS twice.  In both the first and the last pass thread t owns
+// points  t + m*N/8, m = 0..7  -- consecutive lanes touch consecutive samples, so
+// the surrounding global loads/stores are coalesced.
+//
+// LDS layout: point i lives at index i + i/8 (one pad per 8 points) which makes
+// the strided Stockham stores and the unit-stride loads conflict-free for
+// ds_{read,write}_b64.  Two buffers alternate so each exchange costs one barrier.
+#pragma once
+#include "common.h"
+
+__host__ __device__ constexpr int fft_lds_points(int n) { return n + n / 8; }
+// LDS bytes one transform needs (two buffers)
+__host__ __device__ constexpr int fft_lds_bytes(int n) { return 2 * fft_lds_points(n) * (int)sizeof(c32); }
+
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
+
+template <bool INV>
+__device__ __forceinline__ c32 mul_mi(c32 a) {  // forward: a * (-i) ; inverse: a * (+i)
+  return INV ? mk(-a.im, a.re) : mk(a.im, -a.re);
+}
+
+// X[r] = sum_q v[q] * w8^(q r), w8 = exp(-/+ 2 pi i / 8); in place
+template <bool INV>
+__device__ __forceinline__ void dft8(c32 v[8]) {
+  const float h = 0.70710678118654752440f;
+  c32 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+  c32 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+  c32 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+  c32 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+  // odd branch twiddles w8^1, w8^2, w8^3
+  if (INV) {
+    a5 = mk((a5.re - a5.im) * h, (a5.re + a5.im) * h);
+    a7 = mk((-a7.re - a7.im) * h, (a7.re - a7.im) * h);
+  } else {
+    a5 = mk((a5.re + a5.im) * h, (a5.im - a5.re) * h);
+    a7 = mk((a7.im - a7.re) * h, (-a7.re - a7.im) * h);
+  }
+  a6 = mul_mi<INV>(a6);
+  c32 b0 = cadd(a0, a2), b2 = csub(a0, a2);
+  c32 b1 = cadd(a1, a3), b3 = mul_mi<INV>(csub(a1, a3));
+  c32 c0 = cadd(a4, a6), c2 = csub(a4, a6);
+  c32 c1 = cadd(a5, a7), c3 = mul_mi<INV>(csub(a5, a7));
+  v[0] = cadd(b0, b1);
+  v[4] = csub(b0, b1);
+  v[2] = cadd(b2, b3);
+  v[6] = csub(b2, b3);
+  v[1] = cadd(c0, c1);
+  v[5] = csub(c0, c1);
+  v[3] = cadd(c2, c3);
+  v[7] = csub(c2, c3);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(c32& v0, c32& v1, c32& v2, c32& v3) {
+  c32 s0 = cadd(v0, v2), d0 = csub(v0, v2);
+  c32 s1 = cadd(v1, v3), d1 = mul_mi<INV>(csub(v1, v3));
+  v0 = cadd(s0, s1);
+  v2 = csub(s0, s1);
+  v1 = cadd(d0, d1);
+  v3 = csub(d0, d1);
+}
+
+__device__ __forceinline__ void dft2(c32& v0, c32& v1) {
+  c32 s = cadd(v0, v1), d = csub(v0, v1);
+  v0 = s;
+  v1 = d;
+}
+
+// twiddle exp(-/+ 2 pi i * idx / N) from the forward table
+template <bool INV>
+__device__ __forceinline__ c32 tw_get(const c32* __restrict__ tw, int idx) {
+  c32 w = tw[idx];
+  if (INV) w.im = -w.im;
+  return w;
+}
+
+// One Stockham pass of radix R over sub-transforms of length LS (LS*R divides N).
+// FROM_REG: inputs are e[m] = x[t + m*N/8]; otherwise read from `src` (padded LDS).
+// TO_REG  : outputs end in e[m] = X[t + m*N/8] (only legal for the last pass);
+//           otherwise written to `dst` (padded LDS).
+template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG>
+__device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* dst, const c32* __restrict__ tw) {
+  constexpr int T = N / 8;        // threads per transform
+  constexpr int NB = 8 / R;       // butterflies per thread
+  constexpr int STRIDE = N / R;   // input stride of one butterfly
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const int j = t + b * T;  // butterfly index in [0, N/R)
+    c32 v[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      // j + q*STRIDE = t + (b + q*NB) * T
+      if (FROM_REG)
+        v[q] = e[b + q * NB];
+      else
+        v[q] = src[lpad(j + q * STRIDE)];
+    }
+    const int k = (LS == 1) ? 0 : (j % LS);
+    if (LS > 1) {
+      constexpr int TWS = N / (LS * R);
+#pragma unroll
+      for (int q = 1; q < R; q++) v[q] = cmul_f(v[q], tw_get<INV>(tw, k * q * TWS));
+    }
+    if (R == 8) {
+      dft8<INV>(v);
+    } else if (R == 4) {
+      dft4<INV>(v[0], v[1], v[2], v[3]);
+    } else {
+      dft2(v[0], v[1]);
+    }
+    const int obase = (j - k) * R + k;  // (j / LS) * LS * R + k
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (TO_REG)
+        e[b + r * NB] = v[r];  // LS == N/R here, so obase + r*LS = j + r*STRIDE
+      else
+        dst[lpad(obase + r * LS)] = v[r];
+    }
+  }
+}
+
+// Full transform.  e[m] holds x[t + m*N/8] on entry and X[t + m*N/8] on exit.
+// `lds` points at this transform's 2*fft_lds_points(N) c32 scratch.  SYNC() must
+// synchronise the N/8 threads of the transform (block barrier, or nothing but a
+// compiler fence when they are one wave).
+template <int N, bool INV, typename SyncFn>
+__device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __restrict__ tw, SyncFn sync) {
+  c32* A = lds;
+  c32* B = lds + fft_lds_points(N);
+  if constexpr (N == 64) {
+    fft_pass<64, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<64, 8, 8, INV, false, true>(e, t, A, nullptr, tw);
+  } else if constexpr (N == 128) {
+    fft_pass<128, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<128, 8, 2, INV, false, false>(e, t, A, B, tw);
+    sync();
+    fft_pass<128, 8, 16, INV, false, true>(e, t, B, nullptr, tw);
+  } else if constexpr (N == 256) {
+    fft_pass<256, 4, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<256, 8, 4, INV, false, false>(e, t, A, B, tw);
+    sync();
+    fft_pass<256, 8, 32, INV, false, true>(e, t, B, nullptr, tw);
+  } else if constexpr (N == 512) {
+    fft_pass<512, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<512, 8, 8, INV, false, false>(e, t, A, B, tw);
+    sync();
+    fft_pass<512, 8, 64, INV, false, true>(e, t, B, nullptr, tw);
+  } else if constexpr (N == 1024) {
+    fft_pass<1024, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<1024, 8, 2, INV, false, false>(e, t, A, B, tw);
+    sync();
+    fft_pass<1024, 8, 16, INV, false, false>(e, t, B, A, tw);
+    sync();
+    fft_pass<1024, 8, 128, INV, false, true>(e, t, A, nullptr, tw);
+  } else if constexpr (N == 2048) {
+    fft_pass<2048, 4, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<2048, 8, 4, INV, false, false>(e, t, A, B, tw);
+    sync();
+    fft_pass<2048, 8, 32, INV, false, false>(e, t, B, A, tw);
+    sync();
+    fft_pass<2048, 8, 256, INV, false, true>(e, t, A, nullptr, tw);
+  } else {
+    static_assert(N == 4096, "unsupported FFT length");
+    fft_pass<4096, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<4096, 8, 8, INV, false, false>(e, t, A, B, tw);
+    sync();
+    fft_pass<4096, 8, 64, INV, false, false>(e, t, B, A, tw);
+    sync();
+    fft_pass<4096, 8, 512, INV, false, true>(e, t, A, nullptr, tw);
+  }
+}

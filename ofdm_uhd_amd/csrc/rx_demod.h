@@ -1,0 +1,574 @@
+// rx_demod.h -- everything after the timing flags.
+//
+//   k_frames    closed forms of gr_sample_and_hold_ff + gr_frequency_modulator_fc and of the
+//               digital_ofdm_sampler automaton (ofdm_receiver.py~:123-125,133-136): every flag
+//               that the sampler can see starts a frame; its number of data symbols depends only
+//               on the next flag, the time-out and the end of the stream.
+//   k_rx_demod  one workgroup (N/8 threads) per frame: gather N samples past the CP, derotate by
+//               the NCO phase, FFT (LDS), frame acquisition (coarse offset + one-tap equaliser),
+//               frame sink (PLL + DFE + slicer + bit packing + header parse).
+//   chains      a frame sink that is still collecting a packet when the next preamble arrives
+//               treats that preamble as data (digital_ofdm_frame_sink::work has no resync in
+//               HAVE_SYNC / HAVE_HEADER).  Every frame is demodulated optimistically as if the
+//               sink were searching; frames that turn out to be swallowed by an earlier packet are
+//               invalidated afterwards (k_chain_*).
+//   k_deframe   unmake_packet (ofdm_packet_utils.py:169-191): dewhiten, CRC-32 check, compaction
+//               of the (ok, payload) pairs in stream order.
+#pragma once
+#include "common.h"
+#include "fft.h"
+#include "host_util.h"
+
+#define RAW_SLOT 4096  // bytes of frame-sink message storage per frame (MAX_PKT_LEN)
+
+enum { FR_BAD_HEADER = 0, FR_COMPLETE = 1, FR_INCOMPLETE = 2 };
+
+struct FrameResult {
+  uint32_t status;     // FR_*
+  uint32_t packetlen;  // header length field (valid when status != BAD_HEADER and header parsed)
+  uint32_t end_frame;  // frame index in which the sink went back to SYNC_SEARCH (own index if none)
+  uint32_t header_ok;
+};
+
+struct FramesParams {
+  uint64_t npeaks, nsamples;
+  int N, L;
+  uint32_t timeout;
+  float sens;  // float(-2/N)
+  const uint64_t* peaks;
+  const c32* peak_P;
+  float* angle;     // [npeaks]
+  double* step;     // [npeaks]
+  double* inc;      // [npeaks] phase advance until the next flag
+  uint32_t* K;      // [npeaks] data symbols of the frame
+  uint64_t* nsym;   // [npeaks] K+1 for accepted frames else 0 (scanned into symbol ordinals)
+  unsigned int* n_lo;   // flags before the sampler's first window (p < N)
+  unsigned int* n_hi;   // flags the sampler never reaches (end of stream)
+};
+
+__device__ __forceinline__ uint32_t sampler_K(uint64_t p, bool has_next, uint64_t nxt, uint64_t ns, int L, uint32_t timeout) {
+  uint64_t k = (uint64_t)timeout + 1;
+  const uint64_t ks = (ns >= p + 2) ? (ns - p - 2) / (uint64_t)L : 0;
+  if (ks < k) k = ks;
+  if (has_next) {
+    const uint64_t kn = (nxt - p - 2) / (uint64_t)L;  // nxt >= p + 1; (nxt-p-2) may wrap for nxt == p+1
+    if (nxt >= p + 2) {
+      if (kn < k) k = kn;
+    } else {
+      k = 0;
+    }
+  }
+  return (uint32_t)k;
+}
+
+__global__ void __launch_bounds__(256) k_frames(FramesParams q) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= q.npeaks) return;
+  const uint64_t p = q.peaks[j];
+  const c32 P = q.peak_P[j];
+  const float ang = atan2f(P.im, P.re);
+  q.angle[j] = ang;
+  const double st = (double)(q.sens * ang);
+  q.step[j] = st;
+  const bool has_next = j + 1 < q.npeaks;
+  const uint64_t nxt = has_next ? q.peaks[j + 1] : 0;
+  q.inc[j] = has_next ? st * (double)(nxt - p) : 0.0;
+
+  const uint64_t N = (uint64_t)q.N, L = (uint64_t)q.L;
+  bool accept = p >= N;
+  if (!accept) atomicAdd(q.n_lo, 1u);
+  uint64_t b;  // base of the sampler call that finds this flag
+  const bool prev_acc = j > 0 && q.peaks[j - 1] >= N;
+  if (prev_acc) {
+    const uint64_t pp = q.peaks[j - 1];
+    const uint32_t pK = sampler_K(pp, true, p, q.nsamples, q.L, q.timeout);
+    const uint64_t bnext = pp - N + 1 + (uint64_t)pK * L;  // base after the previous frame's last symbol
+    if (pK == q.timeout + 1) {
+      // previous frame timed out: NO_SIG windows of L+1 from there
+      const uint64_t m = (p - N - bnext) / (L + 1);
+      b = bnext + m * (L + 1);
+    } else {
+      b = bnext;
+    }
+  } else {
+    b = accept ? ((p - N) / (L + 1)) * (L + 1) : 0;
+  }
+  if (accept && !(b + L + N < q.nsamples)) {
+    accept = false;
+    atomicAdd(q.n_hi, 1u);
+  }
+  const uint32_t K = accept ? sampler_K(p, has_next, nxt, q.nsamples, q.L, q.timeout) : 0;
+  q.K[j] = K;
+  q.nsym[j] = accept ? (uint64_t)K + 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------
+struct DemodParams {
+  int N, CP, L, occ, zl, nmap, nbits, arity, shift;
+  float phase_gain, freq_gain, eq_gain;
+  uint64_t nsamples;
+  uint32_t j0, nframes, npeaks;  // frames are peaks[j0 .. j0+nframes)
+  int tap_mode;                  // 0: optimistic pass over all frames; 1: tap pass over valid frames
+  const c32* y;
+  const uint64_t* peaks;
+  const double* Phi;   // [npeaks] NCO phase of the sample just before flag j takes effect
+  const double* step;  // [npeaks]
+  const uint32_t* K;   // [npeaks]
+  const uint64_t* sym_base;  // [npeaks] ordinal of the frame's preamble among emitted symbols
+  const c32* tw;
+  const c32* ks;        // [occ]
+  const float* kd;      // [occ]
+  const int16_t* smap;  // [nmap]
+  const c32* constellation;
+  const uint8_t* invalid;  // [nframes] (tap pass)
+  FrameResult* res;        // [nframes]
+  uint8_t* raw;            // [nframes][RAW_SLOT]
+  c32* tap_fft;            // optional [nsym][N]
+  c32* tap_acq;            // optional [nsym][occ]
+  c32* tap_sink;           // optional [nsym][occ]
+  uint8_t* tap_demapped;   // optional [nsym]
+};
+
+template <int N>
+__host__ __device__ constexpr int demod_lds_bytes(int occ) {
+  // fft (2 buffers) | hinv[occ] | dfe[occ] | sd/red scratch [N floats + 64] | bits [1536 words] | misc
+  return fft_lds_bytes(N) + 2 * occ * (int)sizeof(c32) + (N + 64) * (int)sizeof(float) + 1536 * 4 + 256;
+}
+
+// sum over the N/8 threads of the frame
+template <int T>
+__device__ __forceinline__ float block_sum_f(float v, float* red) {
+  if (T >= WAVE) {
+    v = wave_sum(v);
+    if (lane_id() == 0) red[wave_id()] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < T / WAVE; i++) s += red[i];
+    __syncthreads();
+    return s;
+  } else {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < T; i++) s += red[i];
+    __syncthreads();
+    return s;
+  }
+}
+
+template <int N>
+__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodParams q) {
+  constexpr int T = N / 8;
+  extern __shared__ __align__(16) unsigned char smem[];
+  c32* fftbuf = reinterpret_cast<c32*>(smem);
+  c32* Ysh = fftbuf;  // the first FFT buffer is free again after the last pass: shifted spectrum, linear
+  c32* hinv = fftbuf + 2 * fft_lds_points(N);
+  c32* dfe = hinv + q.occ;
+  float* sd = reinterpret_cast<float*>(dfe + q.occ);
+  float* red = sd + N;
+  uint32_t* bits32 = reinterpret_cast<uint32_t*>(red + 64);
+  int* misc = reinterpret_cast<int*>(bits32 + 1536);
+
+  const int t = threadIdx.x;
+  const uint32_t f = blockIdx.x;
+  if (q.tap_mode && q.invalid[f]) return;
+
+  // sink state (uniform across the block)
+  int sstate = 0;  // 0 search, 1 have_sync, 2 have_header
+  float pll_phase = 0.f, pll_freq = 0.f;
+  uint32_t nbits_total = 0;  // bits demapped since enter_have_sync
+  uint32_t packetlen = 0, header_ok = 0;
+  bool done = false;      // sink went back to search
+  uint32_t status = FR_INCOMPLETE;
+  uint32_t end_frame = f;
+  int coarse = 0;
+  unsigned phase_count = 1;
+
+  for (int i = t; i < 1536; i += T) bits32[i] = 0;
+  for (int i = t; i < q.occ; i += T) {
+    hinv[i] = mk(0.f, 0.f);
+    dfe[i] = mk(1.f, 0.f);
+  }
+  __syncthreads();
+
+  uint32_t cf = f;  // frame whose symbols are being consumed
+  for (;;) {
+    const uint32_t j = q.j0 + cf;
+    const uint64_t p = q.peaks[j];
+    const uint32_t K = q.K[j];
+    const double Phi = q.Phi[j], st = q.step[j];
+    const uint64_t symb = q.sym_base[j];
+    for (uint32_t k = 0; k <= K; k++) {
+      if (done && !q.tap_mode) break;
+      const uint64_t s0 = p + (uint64_t)k * (uint64_t)q.L - (uint64_t)N + 1;
+      // ---- sigmix: chan_filt * exp(j phi[n]) ---------------------------------------------
+      c32 e[8];
+      if (k > 0) {
+        // all N samples lie after flag j and before flag j+1: one NCO segment, closed form
+        double ph0 = Phi + st * (double)((int64_t)(s0 + (uint64_t)t) - (int64_t)p + 1);
+        ph0 = ph0 - 6.283185307179586476925 * floor(ph0 / 6.283185307179586476925 + 0.5);
+        double bs, bc;
+        sincos(ph0, &bs, &bc);
+        double ws_, wc_;
+        sincos(st * (double)T, &ws_, &wc_);
+        double rc = 1.0, rs = 0.0;  // exp(j * st * m * T)
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const double cr = bc * rc - bs * rs, ci = bc * rs + bs * rc;
+          const c32 v = q.y[s0 + (uint64_t)(t + m * T)];
+          e[m] = cmul(v, mk((float)cr, (float)ci));
+          const double nrc = rc * wc_ - rs * ws_, nrs = rc * ws_ + rs * wc_;
+          rc = nrc;
+          rs = nrs;
+        }
+      } else {
+        // the preamble symbol ends ON the flag: its samples belong to earlier NCO segments
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const uint64_t n = s0 + (uint64_t)(t + m * T);
+          int64_t i = (int64_t)j;
+          while (i >= 0 && q.peaks[i] > n) i--;
+          double ph = 0.0;
+          if (i >= 0) ph = q.Phi[i] + q.step[i] * (double)(n - q.peaks[i] + 1);
+          ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
+          double sn, cs;
+          sincos(ph, &sn, &cs);
+          e[m] = cmul(q.y[n], mk((float)cs, (float)sn));
+        }
+      }
+      // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
+      fft_run<N, false>(e, t, fftbuf, q.tw, [] { __syncthreads(); });
+      __syncthreads();  // the last pass read buffer B/A: every thread done before Ysh (= A) is overwritten
+#pragma unroll
+      for (int m = 0; m < 8; m++) Ysh[(t + m * T + N / 2) & (N - 1)] = e[m];
+      __syncthreads();
+      if (q.tap_fft) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) q.tap_fft[(symb + k) * (uint64_t)N + (uint64_t)(t + m * T)] = Ysh[t + m * T];
+      }
+
+      // ---- digital_ofdm_frame_acquisition ------------------------------------------------------
+      if (k == 0) {
+        phase_count = 1;
+        // correlate(): sd[i] = |Y[i] - Y[i+2]|^2
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int i = t + m * T;
+          float v = 0.f;
+          if (i < N - 2) v = cnorm(csub(Ysh[i], Ysh[i + 2]));
+          sd[i] = v;
+        }
+        __syncthreads();
+        int index = 0;
+        float mx = 0.f;
+        for (int i0 = q.zl - q.shift; i0 < q.zl + q.shift; i0++) {
+          float part = 0.f;
+          for (int jj = t; jj < q.occ; jj += T) {
+            const int qi = i0 + jj;
+            const float s2 = (qi >= 0 && qi < N) ? sd[qi] : 0.f;
+            part = part + q.kd[jj] * s2;
+          }
+          const float sum = block_sum_f<T>(part, red);
+          if (sum > mx) {
+            mx = sum;
+            index = i0;
+          }
+        }
+        coarse = index - q.zl;
+        // calculate_equalizer()
+        {
+          const double a = -6.283185307179586476925 * (double)coarse * (double)q.CP / (double)N * 1.0;
+          const float af = (float)a;
+          const c32 comp = mk(cosf(af), sinf(af));
+          for (int i = 2 * t; i < q.occ; i += 2 * T) {
+            const int yi = i + q.zl + coarse;
+            const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
+            hinv[i] = cdiv(q.ks[i], cmul(comp, Y));
+          }
+          __syncthreads();
+          for (int i = 2 * t + 1; i < q.occ; i += 2 * T) {
+            if (i + 1 < q.occ) {
+              const c32 a1 = hinv[i + 1], a0 = hinv[i - 1];
+              hinv[i] = mk((a1.re + a0.re) / 2.0f, (a1.im + a0.im) / 2.0f);
+            }
+          }
+          __syncthreads();
+          if (t == 0 && !(q.occ & 1)) hinv[q.occ - 1] = hinv[q.occ - 2];
+          __syncthreads();
+        }
+      }
+      c32 comp;
+      {
+        const double a = -6.283185307179586476925 * (double)coarse * (double)q.CP / (double)N * (double)phase_count;
+        const float af = (float)a;
+        comp = mk(cosf(af), sinf(af));
+        phase_count++;
+        if (phase_count == 1000) phase_count = 1;
+      }
+      if (q.tap_acq) {
+        for (int i = t; i < q.occ; i += T) {
+          const int yi = i + q.zl + coarse;
+          const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
+          q.tap_acq[(symb + k) * (uint64_t)q.occ + (uint64_t)i] = cmul(cmul(hinv[i], comp), Y);
+        }
+      }
+
+      // ---- digital_ofdm_frame_sink::work ------------------------------------------------------------
+      if (done) continue;  // tap pass: the sink is searching again, nothing more to demap in this chain
+      if (sstate == 0) {
+        // only reachable on the chain's first symbol (a preamble): enter_have_sync
+        sstate = 1;
+        continue;
+      }
+      // demapper
+      const c32 carrier = mk(cosf(pll_phase), sinf(pll_phase));
+      c32 accp = mk(0.f, 0.f);
+      for (int c = t; c < q.nmap; c += T) {
+        const int i = q.smap[c];
+        const int yi = i + q.zl + coarse;
+        const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
+        const c32 in = cmul(cmul(hinv[i], comp), Y);
+        const c32 sigrot = cmul(cmul(in, carrier), dfe[c]);
+        // slicer: first minimum of |x - pos[j]|^2
+        unsigned best = 0;
+        float bestd = cnorm(csub(sigrot, q.constellation[0]));
+        for (int jj = 1; jj < q.arity; jj++) {
+          const float dd = cnorm(csub(sigrot, q.constellation[jj]));
+          if (dd < bestd) {
+            bestd = dd;
+            best = (unsigned)jj;
+          }
+        }
+        const c32 closest = q.constellation[best];
+        const c32 er = cmul_conj(sigrot, closest);
+        accp.re = accp.re + er.re;
+        accp.im = accp.im + er.im;
+        if (cnorm(sigrot) > 0.001f) {
+          const c32 qq = cdiv(closest, sigrot);
+          c32 d = dfe[c];
+          d.re = d.re + q.eq_gain * (qq.re - d.re);
+          d.im = d.im + q.eq_gain * (qq.im - d.im);
+          dfe[c] = d;
+        }
+        if (q.tap_sink) q.tap_sink[(symb + k) * (uint64_t)q.occ + (uint64_t)c] = sigrot;
+        // LSB-first bit packing into the message buffer
+        const uint32_t bp = nbits_total + (uint32_t)c * (uint32_t)q.nbits;
+        if ((bp >> 5) < 1535u) {
+          atomicOr(&bits32[bp >> 5], best << (bp & 31));
+          if ((bp & 31) + (uint32_t)q.nbits > 32u) atomicOr(&bits32[(bp >> 5) + 1], best >> (32 - (bp & 31)));
+        }
+      }
+      if (q.tap_demapped && t == 0) q.tap_demapped[symb + k] = 1;
+      const float are = block_sum_f<T>(accp.re, red);
+      const float aim = block_sum_f<T>(accp.im, red);
+      const float angle = atan2f(aim, are);
+      pll_freq = pll_freq - q.freq_gain * angle;
+      pll_phase = pll_phase + pll_freq - q.phase_gain * angle;
+      if (pll_phase >= 6.28318530717958647692f) pll_phase -= 6.28318530717958647692f;
+      if (pll_phase < 0.0f) pll_phase += 6.28318530717958647692f;
+      nbits_total += (uint32_t)q.nmap * (uint32_t)q.nbits;
+      __syncthreads();  // bits32 complete for this symbol
+      const uint32_t nbytes = nbits_total >> 3;
+      if (sstate == 1 && nbytes >= 4) {
+        const uint32_t w = bits32[0];
+        // bytes arrive in order b0..b3; the header is assembled MSB first
+        const uint32_t hdr = ((w & 0xFF) << 24) | (((w >> 8) & 0xFF) << 16) | (((w >> 16) & 0xFF) << 8) | (w >> 24);
+        if (((hdr >> 16) ^ (hdr & 0xFFFF)) == 0) {
+          header_ok = 1;
+          packetlen = (hdr >> 16) & 0x0FFF;
+          sstate = 2;
+        } else {
+          status = FR_BAD_HEADER;
+          done = true;
+          end_frame = cf;
+        }
+      }
+      if (sstate == 2 && nbytes >= 4 + packetlen) {
+        status = FR_COMPLETE;
+        done = true;
+        end_frame = cf;
+      }
+    }
+    if (done && !q.tap_mode) break;
+    if (done && q.tap_mode) break;  // remaining symbols of frame cf were tapped in the loop above
+    if (cf + 1 >= q.nframes) break;
+    cf++;  // the next preamble arrives while the sink is not searching: it is consumed as data
+  }
+  if (!done) end_frame = q.nframes - 1;
+
+  if (!q.tap_mode) {
+    // message bytes (after the 4 header bytes) -> raw slot, word-wise
+    if (status == FR_COMPLETE) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(q.raw + (uint64_t)f * RAW_SLOT);
+      const uint32_t nw = (packetlen + 3) >> 2;
+      for (uint32_t i = t; i < nw; i += T) dst[i] = bits32[1 + i];
+    }
+    if (t == 0) {
+      FrameResult r;
+      r.status = status;
+      r.packetlen = packetlen;
+      r.end_frame = end_frame;
+      r.header_ok = header_ok;
+      q.res[f] = r;
+    }
+  }
+  (void)misc;
+}
+
+// ------------------------------------------------------------------------------------
+// chain resolution: frames swallowed by an earlier, still unfinished packet are invalid
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_chain_collect(const FrameResult* __restrict__ res, uint32_t nframes,
+                                                        uint32_t* __restrict__ list, uint32_t cap, unsigned int* count) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nframes) return;
+  if (res[f].end_frame > f) {
+    const unsigned int k = atomicAdd(count, 1u);
+    if (k < cap) list[k] = f;
+  }
+}
+
+// single thread: sort the (short) list of chain heads, walk it, mark swallowed frames
+__global__ void k_chain_resolve(const FrameResult* __restrict__ res, uint32_t nframes, uint32_t* __restrict__ list,
+                                uint32_t cap, const unsigned int* __restrict__ count, uint8_t* __restrict__ invalid,
+                                unsigned int* overflow) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  unsigned int n = *count;
+  if (n > cap) {
+    atomicOr(overflow, 2u);
+    n = cap;
+  }
+  for (unsigned int i = 1; i < n; i++) {  // insertion sort
+    const uint32_t v = list[i];
+    int k = (int)i - 1;
+    while (k >= 0 && list[k] > v) {
+      list[k + 1] = list[k];
+      k--;
+    }
+    list[k + 1] = v;
+  }
+  int64_t cover = -1;
+  for (unsigned int i = 0; i < n; i++) {
+    const uint32_t f = list[i];
+    if ((int64_t)f <= cover) continue;  // itself swallowed: its optimistic result does not count
+    const uint32_t e = res[f].end_frame;
+    for (uint32_t g = f + 1; g <= e && g < nframes; g++) invalid[g] = 1;
+    cover = (int64_t)e;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// unmake_packet
+// ------------------------------------------------------------------------------------
+struct DeframeParams {
+  uint32_t nframes;
+  const FrameResult* res;
+  const uint8_t* invalid;
+  const uint8_t* raw;
+  const uint8_t* mask;
+  const uint32_t* crc_table;
+  uint64_t* key;        // [nframes] (is_message << 40) | payload_bytes
+  const uint64_t* pos;  // exclusive scan of key
+  uint8_t* payload_out;
+  uint64_t payload_cap;
+  uint64_t* out_off;  // [max_pkts+1]
+  uint32_t* out_len;  // [max_pkts]
+  uint8_t* out_ok;    // [max_pkts]
+  uint32_t max_pkts;
+  uint8_t* raw_tap;       // optional: concatenated messages before dewhitening
+  uint64_t* counters;     // [0] headers_ok [1] packets [2] crc_ok [3] chained [4] capacity overflow
+};
+
+__global__ void __launch_bounds__(256) k_deframe_count(DeframeParams q) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= q.nframes) return;
+  uint64_t key = 0;
+  if (q.invalid[f]) {
+    atomicAdd((unsigned long long*)&q.counters[3], 1ull);
+  } else {
+    const FrameResult r = q.res[f];
+    if (r.header_ok) atomicAdd((unsigned long long*)&q.counters[0], 1ull);
+    if (r.status == FR_COMPLETE) {
+      const uint64_t plen = r.packetlen >= 4 ? r.packetlen - 4 : 0;
+      key = (1ull << 40) | plen;
+    }
+  }
+  q.key[f] = key;
+}
+
+__global__ void __launch_bounds__(256) k_deframe_write(DeframeParams q) {
+  __shared__ uint32_t tab[256];
+  tab[threadIdx.x] = q.crc_table[threadIdx.x];
+  __syncthreads();
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= q.nframes) return;
+  if (q.invalid[f]) return;
+  const FrameResult r = q.res[f];
+  if (r.status != FR_COMPLETE) return;
+  const uint64_t pos = q.pos[f];
+  const uint64_t ord = pos >> 40, boff = pos & ((1ull << 40) - 1);
+  const uint32_t len = r.packetlen;
+  const uint32_t plen = len >= 4 ? len - 4 : 0;
+  if (ord >= q.max_pkts || boff + plen > q.payload_cap) {
+    atomicAdd((unsigned long long*)&q.counters[4], 1ull);
+    return;
+  }
+  const uint8_t* msg = q.raw + (uint64_t)f * RAW_SLOT;
+  uint8_t* out = q.payload_out + boff;
+  // dewhiten with offset 0 (ofdm.py:303 passes no offset) and check the CRC (crc.check_crc32)
+  int ok = 0;
+  if (len >= 4) {
+    uint32_t crc = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < plen; i++) {
+      const uint8_t b = msg[i] ^ q.mask[i];
+      crc = tab[(crc ^ b) & 0xFF] ^ (crc >> 8);
+      out[i] = b;
+    }
+    crc ^= 0xFFFFFFFFu;
+    const uint32_t got = ((uint32_t)(msg[plen] ^ q.mask[plen]) << 24) | ((uint32_t)(msg[plen + 1] ^ q.mask[plen + 1]) << 16) |
+                         ((uint32_t)(msg[plen + 2] ^ q.mask[plen + 2]) << 8) | (uint32_t)(msg[plen + 3] ^ q.mask[plen + 3]);
+    ok = (crc == got);
+  }
+  q.out_off[ord] = boff;
+  q.out_len[ord] = plen;
+  q.out_ok[ord] = (uint8_t)ok;
+  atomicAdd((unsigned long long*)&q.counters[1], 1ull);
+  if (ok) atomicAdd((unsigned long long*)&q.counters[2], 1ull);
+}
+
+// raw (pre-dewhitening) messages, concatenated in stream order, for the PACKETS tap
+__global__ void __launch_bounds__(256) k_raw_tap(DeframeParams q, const uint64_t* __restrict__ rawpos, uint8_t* __restrict__ dst) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= q.nframes) return;
+  if (q.invalid[f]) return;
+  const FrameResult r = q.res[f];
+  if (r.status != FR_COMPLETE) return;
+  const uint8_t* msg = q.raw + (uint64_t)f * RAW_SLOT;
+  for (uint32_t i = 0; i < r.packetlen; i++) dst[rawpos[f] + i] = msg[i];
+}
+__global__ void __launch_bounds__(256) k_raw_len(DeframeParams q, uint64_t* __restrict__ lens) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= q.nframes) return;
+  uint64_t l = 0;
+  if (!q.invalid[f] && q.res[f].status == FR_COMPLETE) l = q.res[f].packetlen;
+  lens[f] = l;
+}
+
+// ------------------------------------------------------------------------------------
+// receive-side workspaces
+// ------------------------------------------------------------------------------------
+struct RxState {
+  DevBuf x_stage, y, metric, tile_B, tile_np, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
+      partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
+      out_payload, out_off, out_len, out_ok, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
+  uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
+  void release() {
+    DevBuf* all[] = {&x_stage, &y,      &metric,  &tile_B,   &tile_np,  &tile_pieces, &avg_in,     &cand_u,
+                     &cand_P,  &counters, &counts, &offsets,  &partial,  &peaks,       &peak_P,     &angle,
+                     &step,    &inc,    &Phi,     &K,        &nsym,     &sym_base,    &res,        &raw,
+                     &invalid, &chain_list, &key, &pos,      &out_payload, &out_off,  &out_len,    &out_ok,
+                     &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
+    for (DevBuf* b : all) b->release();
+  }
+};

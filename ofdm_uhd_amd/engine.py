@@ -1,0 +1,243 @@
+"""Thin Python wrapper over the C ABI of libofdm_hip.so (include/ofdm_hip.h).
+
+``Engine`` owns one ``ofdm_handle`` (one GPU, one HIP stream).  In host mode it
+takes / returns NumPy arrays; in device mode (``device_ptrs=True``) the bulk
+arguments are raw device pointers (e.g. ``torch.Tensor.data_ptr()``), which is
+what bench.py uses so that nothing crosses PCIe inside the timed region.
+
+There is no CPU implementation behind this class: if the library is missing,
+importing fails loudly (see _abi.load).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, config
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libofdm_hip: %s (code %d)" % (msg, code))
+        self.code = code
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack_payloads(payloads):
+    """list of bytes -> (blob uint8, offsets uint64, lengths uint32)"""
+    lens = np.array([len(p) for p in payloads], np.uint32)
+    offs = np.zeros(max(len(payloads), 1), np.uint64)
+    if len(payloads) > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(bytes(p) for p in payloads), np.uint8)
+    if blob.size == 0:
+        blob = np.zeros(1, np.uint8)
+    return np.ascontiguousarray(blob), offs[:len(payloads)] if len(payloads) else offs[:0], lens
+
+
+class Engine(object):
+    def __init__(self, options=None, cfg=None, pad_for_usrp=False, device_ptrs=False, device_id=0, **cfg_kw):
+        self._lib = _abi.load()
+        if cfg is None:
+            cfg = config.make_cfg(options, pad_for_usrp=pad_for_usrp, device_ptrs=device_ptrs,
+                                  device_id=device_id, **cfg_kw)
+        self.cfg = cfg
+        self.device_ptrs = bool(cfg.flags & _abi.OFDM_F_DEVICE_PTRS)
+        self._h = C.c_void_p(None)
+        rc = self._lib.ofdm_create(C.byref(cfg), C.byref(self._h))
+        if rc != _abi.OFDM_OK:
+            msg = self._lib.ofdm_last_error(None)
+            self._h = C.c_void_p(None)
+            if rc == _abi.OFDM_E_INVAL:
+                raise ValueError((msg or b"").decode())
+            raise EngineError(rc, (msg or b"").decode())
+        self.N = cfg.fft_length
+        self.CP = cfg.cp_length
+        self.L = self.N + self.CP
+        self.occ = cfg.occupied_tones
+        self.last_stats = {}
+
+    # -- plumbing ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ofdm_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == _abi.OFDM_OK:
+            return
+        msg = (self._lib.ofdm_last_error(self._h) or b"").decode()
+        if rc == _abi.OFDM_E_INVAL:
+            raise ValueError(msg)
+        raise EngineError(rc, msg)
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.ofdm_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def set_tx_amplitude(self, ampl):
+        self._check(self._lib.ofdm_set_tx_amplitude(self._h, float(ampl)))
+
+    def set_channel(self, sigma=0.0, cfo=0.0, seed=0xC0FFEE, stream_id=0, lead=0, tail=0, enable=True):
+        if not enable:
+            self._check(self._lib.ofdm_set_channel(self._h, None))
+            return
+        ch = _abi.ofdm_chan(sigma=sigma, cfo=cfo, seed=seed, stream_id=stream_id, lead_samples=lead,
+                            tail_samples=tail)
+        self._check(self._lib.ofdm_set_channel(self._h, C.byref(ch)))
+
+    def set_taps(self, *taps):
+        mask = 0
+        for t in taps:
+            mask |= 1 << t
+        self._check(self._lib.ofdm_set_taps(self._h, mask))
+
+    def prof_enable(self, on=True):
+        self._check(self._lib.ofdm_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._check(self._lib.ofdm_prof_reset(self._h))
+
+    def prof(self):
+        out = {}
+        for k in range(_abi.K_COUNT):
+            ms = C.c_double(0)
+            n = C.c_uint64(0)
+            self._check(self._lib.ofdm_prof_get(self._h, k, C.byref(ms), C.byref(n)))
+            out[self._lib.ofdm_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    # -- framing ----------------------------------------------------------------
+    def framed_len(self, payload_len):
+        n = C.c_uint32(0)
+        self._check(self._lib.ofdm_framed_len(self._h, int(payload_len), C.byref(n)))
+        return n.value
+
+    def make_packets(self, payloads):
+        """Batched make_packet; host mode only.  Returns list of bytes."""
+        assert not self.device_ptrs
+        blob, offs, lens = pack_payloads(payloads)
+        total = 0
+        for ln in lens:
+            total += self.framed_len(int(ln))
+        out = np.zeros(max(total, 1), np.uint8)
+        foff = np.zeros(len(payloads) + 1, np.uint64)
+        self._check(self._lib.ofdm_make_packets(self._h, _ptr(blob), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                lens.ctypes.data_as(C.POINTER(C.c_uint32)), len(payloads), _ptr(out),
+                                                len(out), foff.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return [out[int(foff[i]):int(foff[i + 1])].tobytes() for i in range(len(payloads))]
+
+    # -- TX ----------------------------------------------------------------------
+    def tx_frame_count(self, lens):
+        lens = np.ascontiguousarray(lens, np.uint32)
+        nsym = C.c_uint64(0)
+        nsamp = C.c_uint64(0)
+        self._check(self._lib.ofdm_tx_frame_count(self._h, lens.ctypes.data_as(C.POINTER(C.c_uint32)), len(lens),
+                                                  C.byref(nsym), C.byref(nsamp)))
+        return nsym.value, nsamp.value
+
+    def tx(self, payloads):
+        """Host mode: list of payload bytes -> complex64 IQ (incl. channel lead/tail if set)."""
+        assert not self.device_ptrs
+        blob, offs, lens = pack_payloads(payloads)
+        _, nsamp = self.tx_frame_count(lens)
+        iq = np.zeros(max(nsamp, 1), np.complex64)
+        ns = C.c_uint64(0)
+        st = _abi.ofdm_stats()
+        self._check(self._lib.ofdm_tx(self._h, _ptr(blob), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      lens.ctypes.data_as(C.POINTER(C.c_uint32)), len(payloads), _ptr(iq), len(iq),
+                                      C.byref(ns), C.byref(st)))
+        self.last_stats = st.as_dict()
+        return iq[:ns.value]
+
+    def tx_device(self, payload_ptr, offs, lens, iq_ptr, iq_cap):
+        """Device mode: payload bytes and IQ are device pointers; offs/lens are NumPy host arrays."""
+        assert self.device_ptrs
+        ns = C.c_uint64(0)
+        st = _abi.ofdm_stats()
+        self._check(self._lib.ofdm_tx(self._h, C.c_void_p(payload_ptr), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      lens.ctypes.data_as(C.POINTER(C.c_uint32)), len(lens), C.c_void_p(iq_ptr),
+                                      int(iq_cap), C.byref(ns), C.byref(st)))
+        self.last_stats = st.as_dict()
+        return ns.value
+
+    def channel(self, iq, sigma=0.0, cfo=0.0, seed=0xC0FFEE, stream_id=0, index0=0):
+        """Host mode: returns a new array with the synthetic channel applied."""
+        assert not self.device_ptrs
+        out = np.ascontiguousarray(iq, np.complex64).copy()
+        ch = _abi.ofdm_chan(sigma=sigma, cfo=cfo, seed=seed, stream_id=stream_id, lead_samples=0, tail_samples=0)
+        self._check(self._lib.ofdm_channel(self._h, _ptr(out), len(out), C.byref(ch), index0))
+        return out
+
+    # -- RX ----------------------------------------------------------------------
+    def rx(self, iq, max_pkts=None, payload_cap=None):
+        """Host mode: complex64 IQ -> list of (ok, payload) in stream order, exactly the pairs the
+        reference hands to its rx callback (ofdm.py:300-305)."""
+        assert not self.device_ptrs
+        iq = np.ascontiguousarray(iq, np.complex64)
+        if max_pkts is None:
+            max_pkts = len(iq) // self.L + 16
+        if payload_cap is None:
+            payload_cap = max_pkts * 64 + len(iq)  # bits never exceed 8 per sample
+        pay = np.zeros(max(payload_cap, 1), np.uint8)
+        off = np.zeros(max_pkts + 1, np.uint64)
+        ln = np.zeros(max(max_pkts, 1), np.uint32)
+        ok = np.zeros(max(max_pkts, 1), np.uint8)
+        npk = C.c_int(0)
+        st = _abi.ofdm_stats()
+        rc = self._lib.ofdm_rx(self._h, _ptr(iq) if len(iq) else None, len(iq), _ptr(pay), len(pay),
+                               off.ctypes.data_as(C.POINTER(C.c_uint64)), ln.ctypes.data_as(C.POINTER(C.c_uint32)),
+                               ok.ctypes.data_as(C.POINTER(C.c_uint8)), max_pkts, C.byref(npk), C.byref(st))
+        self.last_stats = st.as_dict()
+        self._check(rc)
+        return [(bool(ok[i]), pay[int(off[i]):int(off[i]) + int(ln[i])].tobytes()) for i in range(npk.value)]
+
+    def rx_device(self, iq_ptr, nsamples, payload_ptr, payload_cap, max_pkts):
+        """Device mode.  Returns (npkt, off, len, ok) with NumPy metadata arrays."""
+        assert self.device_ptrs
+        off = np.zeros(max_pkts + 1, np.uint64)
+        ln = np.zeros(max(max_pkts, 1), np.uint32)
+        ok = np.zeros(max(max_pkts, 1), np.uint8)
+        npk = C.c_int(0)
+        st = _abi.ofdm_stats()
+        rc = self._lib.ofdm_rx(self._h, C.c_void_p(iq_ptr), int(nsamples), C.c_void_p(payload_ptr), int(payload_cap),
+                               off.ctypes.data_as(C.POINTER(C.c_uint64)), ln.ctypes.data_as(C.POINTER(C.c_uint32)),
+                               ok.ctypes.data_as(C.POINTER(C.c_uint8)), int(max_pkts), C.byref(npk), C.byref(st))
+        self.last_stats = st.as_dict()
+        self._check(rc)
+        n = npk.value
+        return n, off[:n + 1], ln[:n], ok[:n]
+
+    # -- taps ---------------------------------------------------------------------
+    _TAP_DTYPES = {
+        _abi.TAP_TX_PACKETS: np.uint8, _abi.TAP_TX_FREQ: np.complex64, _abi.TAP_RX_CHAN_FILT: np.complex64,
+        _abi.TAP_RX_METRIC: np.float32, _abi.TAP_RX_PEAKS: np.uint64, _abi.TAP_RX_ANGLES: np.float32,
+        _abi.TAP_RX_FRAMES: np.uint64, _abi.TAP_RX_FFT: np.complex64, _abi.TAP_RX_ACQ: np.complex64,
+        _abi.TAP_RX_SINK: np.complex64, _abi.TAP_RX_PACKETS: np.uint8,
+    }
+
+    def tap(self, tap):
+        nb = C.c_uint64(0)
+        self._check(self._lib.ofdm_tap(self._h, tap, None, 0, C.byref(nb)))
+        dt = np.dtype(self._TAP_DTYPES[tap])
+        out = np.zeros(nb.value // dt.itemsize, dt)
+        if nb.value:
+            self._check(self._lib.ofdm_tap(self._h, tap, _ptr(out), nb.value, C.byref(nb)))
+        if tap == _abi.TAP_RX_FRAMES:
+            out = out.reshape(-1, 2)
+        elif tap in (_abi.TAP_TX_FREQ, _abi.TAP_RX_FFT):
+            out = out.reshape(-1, self.N)
+        elif tap in (_abi.TAP_RX_ACQ, _abi.TAP_RX_SINK):
+            out = out.reshape(-1, self.occ)
+        return out
+
+
+def device_count():
+    return _abi.load().ofdm_device_count()

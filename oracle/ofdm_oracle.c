@@ -1,0 +1,1058 @@
+/*
+ * ofdm_oracle.c -- CPU restatement of the rubiruchi/ofdm_uhd ofdm_mod/ofdm_demod
+ * hot path.  TEST INFRASTRUCTURE ONLY: it is the parity checker for
+ * libofdm_hip.so and the "port" CPU baseline of bench.py.  Nothing in the
+ * product (ofdm_uhd_amd/) may import, link or call it.
+ *
+ * PARITY UNPINNED at the GNU Radio boundary: the arithmetic of this path lives
+ * in GNU Radio 3.6.0 C++ blocks (gnuradio-core + gr-digital, pinned only by
+ * path comments ofdm.py:29 and the banner output.txt:1) that are neither under
+ * /root/reference nor installed, and the reference has no tests or golden
+ * vectors for them.  Each function below restates the published behaviour of
+ * the block named at the reference call site it cites.
+ * What IS pinned, by tests/golden/reference_constants.json: the constellation
+ * tables (psk.py:27-60, qam.py:29-73), the preamble sequence (ofdm.py:310-325),
+ * the whitening mask (ofdm_packet_utils.py:195-452), the header layout
+ * (ofdm_packet_utils.py:93-97) and CRC-32's standard check value.
+ *
+ * Arithmetic conventions (normative for the HIP engine):
+ *   - gr_complex = float32 pairs at every block boundary.
+ *   - channel filter: causal direct form, one fmaf chain per output in tap
+ *     order k = 0..ntaps-1 (bit-reproducible on the GPU).
+ *   - the three moving sums of ofdm_sync_pn are accumulated in Q23.40 fixed
+ *     point (error <= 2^-41 per term, far below GR's own float32 accumulate),
+ *     which makes them independent of evaluation order, so a parallel GPU
+ *     scan gives the same bits.  0/0 in the metric (silent input) yields 0
+ *     instead of GR's NaN, and M is clamped to 1024.
+ *   - the NCO phase is the closed form of gr_frequency_modulator_fc in float64
+ *     (GR's float32 accumulator with its scheduler-dependent fmod wrap is not
+ *     reproducible by anyone).
+ *   - the mapper's rand()%arity fill is a counter-based hash of
+ *     (pad_seed, packet, carrier slot).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ofdm_hip.h"
+#include "ofdm_oracle.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* small helpers                                                            */
+/* ------------------------------------------------------------------------ */
+
+static inline ofdm_c32 c32(float re, float im) {
+  ofdm_c32 z = {re, im};
+  return z;
+}
+/* gr_complex multiply as volk/SSE does it: two products per part, one add, no fma */
+static inline ofdm_c32 cmul(ofdm_c32 a, ofdm_c32 b) {
+  float re = a.re * b.re - a.im * b.im;
+  float im = a.re * b.im + a.im * b.re;
+  return c32(re, im);
+}
+static inline ofdm_c32 cmul_conj(ofdm_c32 a, ofdm_c32 b) { /* a * conj(b) */
+  float re = a.re * b.re + a.im * b.im;
+  float im = a.im * b.re - a.re * b.im;
+  return c32(re, im);
+}
+static inline ofdm_c32 cdiv(ofdm_c32 a, ofdm_c32 b) {
+  float den = b.re * b.re + b.im * b.im;
+  float re = (a.re * b.re + a.im * b.im) / den;
+  float im = (a.im * b.re - a.re * b.im) / den;
+  return c32(re, im);
+}
+static inline float cnorm(ofdm_c32 a) { return a.re * a.re + a.im * a.im; }
+
+static int ilog2_ceil(unsigned v) {
+  int n = 0;
+  while ((1u << n) < v) n++;
+  return n;
+}
+
+int orc_nbits(const ofdm_cfg *cfg) { return ilog2_ceil(cfg->arity); }
+
+typedef struct {
+  void *p;
+  size_t n, cap, esz;
+} vec;
+static void vec_init(vec *v, size_t esz) {
+  v->p = NULL;
+  v->n = v->cap = 0;
+  v->esz = esz;
+}
+static void *vec_push(vec *v, size_t count) {
+  if (v->n + count > v->cap) {
+    size_t nc = v->cap ? v->cap * 2 : 256;
+    while (nc < v->n + count) nc *= 2;
+    v->p = realloc(v->p, nc * v->esz);
+    if (!v->p) abort();
+    v->cap = nc;
+  }
+  void *r = (char *)v->p + v->n * v->esz;
+  v->n += count;
+  return r;
+}
+static void vec_free(vec *v) {
+  free(v->p);
+  v->p = NULL;
+  v->n = v->cap = 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CRC-32  (digital_crc32 / crc.gen_and_append_crc32, ofdm_packet_utils.py:25,120,184;
+ * docstring digital_swig.py:3151-3169): reflected 0xEDB88320, init/xorout ~0   */
+/* ------------------------------------------------------------------------ */
+static uint32_t crc_table[256];
+static int crc_table_ready = 0;
+static void crc_init(void) {
+  for (uint32_t i = 0; i < 256; i++) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    crc_table[i] = c;
+  }
+  crc_table_ready = 1;
+}
+uint32_t orc_crc32(const uint8_t *buf, uint64_t len) {
+  if (!crc_table_ready) crc_init();
+  uint32_t c = 0xFFFFFFFFu;
+  for (uint64_t i = 0; i < len; i++) c = crc_table[(c ^ buf[i]) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+
+/* ------------------------------------------------------------------------ */
+/* make_packet / unmake_packet  (ofdm_packet_utils.py:84-143,169-191)        */
+/* ------------------------------------------------------------------------ */
+
+/* _npadding_bytes(pkt_byte_len, samples_per_symbol=1, bits_per_symbol=1) as
+ * ofdm_mod.send_pkt calls it (ofdm.py:144): byte_modulus = lcm(128/8,1)*1/1 = 16 */
+static uint32_t npadding_bytes(uint32_t pkt_byte_len) {
+  uint32_t r = pkt_byte_len % 16u;
+  return r == 0 ? 0 : 16u - r;
+}
+
+int orc_framed_len(const ofdm_cfg *cfg, uint32_t payload_len, uint32_t *out) {
+  uint32_t L = payload_len + 4; /* payload + CRC */
+  if (L > OFDM_MASK_LEN) return OFDM_E_INVAL; /* ofdm_packet_utils.py:123-126 */
+  uint32_t n = 4 + L + 1;       /* header + body + 0x55 */
+  if (cfg->flags & OFDM_F_PAD_FOR_USRP) n += npadding_bytes(n);
+  *out = n;
+  return OFDM_OK;
+}
+
+int orc_make_packet(const ofdm_cfg *cfg, const uint8_t *payload, uint32_t len, uint8_t *out,
+                    uint32_t *outlen) {
+  uint32_t n;
+  int rc = orc_framed_len(cfg, len, &n);
+  if (rc) return rc;
+  uint32_t off = cfg->whitener_offset;
+  if (off > 15) return OFDM_E_INVAL; /* ofdm_packet_utils.py:117-118 (intent) */
+  uint32_t L = len + 4;
+  /* make_header: (off & 0xf) << 12 | (L & 0xfff), twice, big endian (ofdm_packet_utils.py:93-97) */
+  uint32_t val = ((off & 0xF) << 12) | (L & 0x0FFF);
+  out[0] = (uint8_t)(val >> 8);
+  out[1] = (uint8_t)val;
+  out[2] = out[0];
+  out[3] = out[1];
+  uint8_t *body = out + 4;
+  memcpy(body, payload, len);
+  uint32_t crc = orc_crc32(payload, len);
+  body[len + 0] = (uint8_t)(crc >> 24); /* struct.pack(">I", crc) */
+  body[len + 1] = (uint8_t)(crc >> 16);
+  body[len + 2] = (uint8_t)(crc >> 8);
+  body[len + 3] = (uint8_t)crc;
+  for (uint32_t i = L; i < n - 4; i++) body[i] = 0x55; /* tail + USRP pad (:129,132-134) */
+  /* whiten(pkt_dt, o): XOR with mask[o : o+len] (ofdm_packet_utils.py:84-87); header is not whitened.
+   * numpy slicing truncates at the mask end: bytes past it would raise a shape error in the
+   * reference; they cannot occur for L <= 4095 + pad within 4096+... we guard instead.      */
+  for (uint32_t i = 0; i < n - 4; i++) {
+    uint32_t m = off + i;
+    if (m >= OFDM_MASK_LEN) return OFDM_E_INVAL;
+    body[i] ^= cfg->whitening_mask[m];
+  }
+  *outlen = n;
+  return OFDM_OK;
+}
+
+/* unmake_packet(msg, whitener_offset=0, dewhitening=1) + crc.check_crc32
+ * (ofdm_packet_utils.py:169-191; called without offset at ofdm.py:303)      */
+int orc_unmake_packet(const ofdm_cfg *cfg, const uint8_t *msg, uint32_t len, uint8_t *payload_out,
+                      uint32_t *payload_len, int *ok) {
+  if (len > OFDM_MASK_LEN) return OFDM_E_INVAL;
+  if (len < 4) { /* check_crc32: len < 4 -> (False, '') */
+    *ok = 0;
+    *payload_len = 0;
+    return OFDM_OK;
+  }
+  uint8_t tmp[OFDM_MASK_LEN];
+  for (uint32_t i = 0; i < len; i++) tmp[i] = msg[i] ^ cfg->whitening_mask[i];
+  uint32_t crc = orc_crc32(tmp, len - 4);
+  uint32_t got = ((uint32_t)tmp[len - 4] << 24) | ((uint32_t)tmp[len - 3] << 16) |
+                 ((uint32_t)tmp[len - 2] << 8) | (uint32_t)tmp[len - 1];
+  *ok = (crc == got);
+  *payload_len = len - 4;
+  memcpy(payload_out, tmp, len - 4);
+  return OFDM_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* subcarrier map  (digital_ofdm_mapper_bcv ctor at ofdm.py:106 with
+ * container = fft_length; digital_ofdm_frame_sink ctor at ofdm.py:240 with
+ * container = occupied_tones).  Default carrier string "FE7F"
+ * (transmit_path.py:64 default, reset_carrier_map commented out :67).        */
+/* ------------------------------------------------------------------------ */
+int orc_carrier_map(int occ, int container, int *map, int cap) {
+  /* hex digit values, MSB = lowest carrier of the nibble */
+  int digits[OFDM_MAX_FFT / 4 + 8];
+  int nd = 0;
+  if (occ < 16 || occ > OFDM_MAX_FFT || container > OFDM_MAX_FFT) return OFDM_E_INVAL;
+  int diff = occ - 16;
+  int nf = 0;
+  while (diff > 7) {
+    nf++;
+    diff -= 8;
+  }
+  int have_extra = diff > 0;
+  int dl = 0, dr = 0;
+  if (have_extra) {
+    dl = (diff + 1) / 2; /* ceil(diff/2) */
+    dr = diff - dl;
+    digits[nd++] = (1 << dl) - 1;
+  }
+  for (int i = 0; i < nf; i++) digits[nd++] = 0xF;
+  digits[nd++] = 0xF;
+  digits[nd++] = 0xE;
+  digits[nd++] = 0x7;
+  digits[nd++] = 0xF;
+  for (int i = 0; i < nf; i++) digits[nd++] = 0xF;
+  if (have_extra) digits[nd++] = 0xF ^ ((1 << dr) - 1);
+  int pad = (container / 4 - nd) / 2; /* C integer division, as the C++ does */
+  int n = 0;
+  for (int i = 0; i < nd; i++)
+    for (int j = 0; j < 4; j++)
+      if ((digits[i] >> (3 - j)) & 1) {
+        int idx = 4 * (i + pad) + j;
+        if (idx < 0 || idx >= container) return OFDM_E_INVAL;
+        if (n >= cap) return OFDM_E_CAPACITY;
+        map[n++] = idx;
+      }
+  if (n > occ) return OFDM_E_INVAL; /* "subcarriers allocated exceeds size of occupied carriers" */
+  return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* FFT: gr_fft_vcc over FFTW3f (ofdm.py:112, ofdm_receiver.py~:126): unnormalised
+ * DFT, float32.  Radix-2 decimation in time, twiddles rounded from float64.  */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int n, logn;
+  float *wr, *wi; /* exp(-2 pi i k / n), k < n/2 */
+  int *rev;
+} fft_plan;
+
+static void fft_plan_init(fft_plan *p, int n) {
+  p->n = n;
+  p->logn = ilog2_ceil((unsigned)n);
+  p->wr = (float *)malloc(sizeof(float) * (size_t)n / 2);
+  p->wi = (float *)malloc(sizeof(float) * (size_t)n / 2);
+  p->rev = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int k = 0; k < n / 2; k++) {
+    double a = -2.0 * M_PI * (double)k / (double)n;
+    p->wr[k] = (float)cos(a);
+    p->wi[k] = (float)sin(a);
+  }
+  for (int i = 0; i < n; i++) {
+    int r = 0;
+    for (int b = 0; b < p->logn; b++)
+      if (i & (1 << b)) r |= 1 << (p->logn - 1 - b);
+    p->rev[i] = r;
+  }
+}
+static void fft_plan_free(fft_plan *p) {
+  free(p->wr);
+  free(p->wi);
+  free(p->rev);
+}
+/* in-place; inverse != 0 uses exp(+...) ; no scaling either way */
+static void fft_exec(const fft_plan *p, ofdm_c32 *x, int inverse) {
+  int n = p->n;
+  for (int i = 0; i < n; i++) {
+    int r = p->rev[i];
+    if (r > i) {
+      ofdm_c32 t = x[i];
+      x[i] = x[r];
+      x[r] = t;
+    }
+  }
+  for (int len = 2; len <= n; len <<= 1) {
+    int half = len >> 1, step = n / len;
+    for (int i = 0; i < n; i += len)
+      for (int k = 0; k < half; k++) {
+        ofdm_c32 w = c32(p->wr[k * step], inverse ? -p->wi[k * step] : p->wi[k * step]);
+        ofdm_c32 u = x[i + k];
+        ofdm_c32 v = cmul(x[i + k + half], w);
+        x[i + k] = c32(u.re + v.re, u.im + v.im);
+        x[i + k + half] = c32(u.re - v.re, u.im - v.im);
+      }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* TX                                                                       */
+/* ------------------------------------------------------------------------ */
+
+/* symbols the mapper emits for one framed packet, excluding the preamble:
+ * a new symbol is started while message bytes remain (digital_ofdm_mapper_bcv::work) */
+uint32_t orc_tx_data_symbols(const ofdm_cfg *cfg, uint32_t framed_len, int ncarriers) {
+  uint64_t bits = 8ull * framed_len;
+  uint64_t per = (uint64_t)ncarriers * (uint64_t)orc_nbits(cfg);
+  return (uint32_t)((bits + per - 1) / per);
+}
+
+/* counter-based replacement for the mapper's  rand() % arity  fill */
+uint32_t orc_pad_symbol(uint64_t seed, uint64_t pkt, uint64_t slot, uint32_t arity) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (pkt + 1) + 0xBF58476D1CE4E5B9ull * (slot + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)((z >> 32) % arity);
+}
+
+/* chunk c (nbits wide) of the little-endian-within-byte bit stream of msg, or -1
+ * when the message cannot supply all nbits (incomplete chunk is dropped)       */
+static int msg_chunk(const uint8_t *msg, uint32_t len, uint64_t c, int nbits) {
+  uint64_t b0 = c * (uint64_t)nbits;
+  if (b0 + (uint64_t)nbits > 8ull * len) return -1;
+  unsigned v = 0;
+  for (int k = 0; k < nbits; k++) {
+    uint64_t b = b0 + (uint64_t)k;
+    v |= (unsigned)((msg[b >> 3] >> (b & 7)) & 1) << k;
+  }
+  return (int)v;
+}
+
+int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload_off,
+           const uint32_t *payload_len, int npkt, uint64_t lead, ofdm_c32 *iq_out, uint64_t iq_cap,
+           uint64_t *nsamples_out, ofdm_c32 *freq_tap, uint8_t *framed_tap, uint64_t *framed_off_tap) {
+  int N = (int)cfg->fft_length, CP = (int)cfg->cp_length, occ = (int)cfg->occupied_tones;
+  int L = N + CP;
+  int nbits = orc_nbits(cfg);
+  if (occ > N) return OFDM_E_INVAL; /* mapper ctor: occupied_carriers > fft_length */
+  int *map = (int *)malloc(sizeof(int) * (size_t)occ);
+  int nc = orc_carrier_map(occ, N, map, occ);
+  if (nc < 0) {
+    free(map);
+    return nc;
+  }
+  int zl = (N - occ + 1) / 2; /* ceil((N-occ)/2), ofdm.py:71 */
+  /* padded preamble (ofdm.py:83-87) */
+  ofdm_c32 *pre = (ofdm_c32 *)calloc((size_t)N, sizeof(ofdm_c32));
+  for (int i = 0; i < occ; i++) pre[zl + i] = cfg->known_symbol[i];
+
+  fft_plan plan;
+  fft_plan_init(&plan, N);
+  ofdm_c32 *sym = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)N);
+  ofdm_c32 *tmp = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)N);
+  uint8_t *pkt = (uint8_t *)malloc(OFDM_MASK_LEN + 64);
+  float scale1 = (float)(1.0 / sqrt((double)N)); /* gr.multiply_const_cc(1.0/math.sqrt(N)), ofdm.py:114 */
+  float amp = cfg->tx_amplitude;                 /* transmit_path.amp, transmit_path.py:48-54 */
+
+  uint64_t pos = lead, nsym_total = 0, foff = 0;
+  int rc = OFDM_OK;
+  for (int p = 0; p < npkt && rc == OFDM_OK; p++) {
+    uint32_t plen;
+    rc = orc_make_packet(cfg, payloads + payload_off[p], payload_len[p], pkt, &plen);
+    if (rc) break;
+    if (framed_tap) {
+      memcpy(framed_tap + foff, pkt, plen);
+      framed_off_tap[p] = foff;
+    }
+    foff += plen;
+    uint32_t nds = orc_tx_data_symbols(cfg, plen, nc);
+    for (uint32_t s = 0; s <= nds; s++) {
+      /* s == 0: ofdm_insert_preamble emits the preamble ahead of the flagged symbol (ofdm.py:111) */
+      if (s == 0) {
+        memcpy(sym, pre, sizeof(ofdm_c32) * (size_t)N);
+      } else {
+        memset(sym, 0, sizeof(ofdm_c32) * (size_t)N);
+        for (int i = 0; i < nc; i++) {
+          uint64_t slot = (uint64_t)(s - 1) * (uint64_t)nc + (uint64_t)i;
+          int bits = msg_chunk(pkt, plen, slot, nbits);
+          if (bits < 0) bits = (int)orc_pad_symbol(cfg->pad_seed, (uint64_t)p, slot, cfg->arity);
+          sym[map[i]] = cfg->constellation[bits];
+        }
+      }
+      if (freq_tap) memcpy(freq_tap + nsym_total * (uint64_t)N, sym, sizeof(ofdm_c32) * (size_t)N);
+      /* gr.fft_vcc(N, False, [], True): swap input halves, unnormalised inverse DFT (ofdm.py:112) */
+      for (int k = 0; k < N; k++) tmp[k] = sym[(k + N / 2) % N];
+      fft_exec(&plan, tmp, 1);
+      if (pos + (uint64_t)L > iq_cap) {
+        rc = OFDM_E_CAPACITY;
+        break;
+      }
+      /* ofdm_cyclic_prefixer(N, N+CP) (ofdm.py:113) then the two multiply_const_cc */
+      ofdm_c32 *o = iq_out + pos;
+      for (int n = 0; n < L; n++) {
+        ofdm_c32 v = tmp[(n + N - CP) % N];
+        v.re = v.re * scale1;
+        v.im = v.im * scale1;
+        v.re = v.re * amp;
+        v.im = v.im * amp;
+        o[n] = v;
+      }
+      pos += (uint64_t)L;
+      nsym_total++;
+    }
+  }
+  if (framed_tap) framed_off_tap[npkt] = foff;
+  *nsamples_out = pos;
+  free(pkt);
+  free(tmp);
+  free(sym);
+  fft_plan_free(&plan);
+  free(pre);
+  free(map);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* synthetic channel (stands in for the UHD sink/source pair)                */
+/* ------------------------------------------------------------------------ */
+static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[4]) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  memcpy(out, c, sizeof(c));
+}
+
+int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0) {
+  const float inv24 = 1.0f / 16777216.0f;
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t idx = index0 + i;
+    ofdm_c32 x = iq[i];
+    if (ch->cfo != 0.0f) {
+      double ph = (double)ch->cfo * (double)idx;
+      ph = ph - 2.0 * M_PI * floor(ph / (2.0 * M_PI) + 0.5);
+      ofdm_c32 r = c32((float)cos(ph), (float)sin(ph));
+      x = cmul(x, r);
+    }
+    if (ch->sigma > 0.0f) {
+      uint32_t r[4];
+      orc_philox(ch->seed, ch->stream_id, idx, r);
+      float u1 = ((float)(r[0] >> 8) + 0.5f) * inv24;
+      float u2 = ((float)(r[1] >> 8) + 0.5f) * inv24;
+      float rad = sqrtf(-2.0f * logf(u1));
+      float th = 6.28318530717958647692f * u2;
+      float s = ch->sigma * 0.70710678118654752440f;
+      x.re = x.re + s * (rad * cosf(th));
+      x.im = x.im + s * (rad * sinf(th));
+    }
+    iq[i] = x;
+  }
+  return OFDM_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* RX                                                                       */
+/* ------------------------------------------------------------------------ */
+struct orc_rx_result {
+  ofdm_stats st;
+  uint32_t tap_mask;
+  int N, occ;
+  vec y;        /* c32 */
+  vec metric;   /* f32 */
+  vec peaks;    /* u64 */
+  vec angles;   /* f32 */
+  vec frames;   /* u64 x2 */
+  vec fft;      /* c32 */
+  vec acq;      /* c32 */
+  vec sink;     /* c32 */
+  vec raw;      /* u8: frame sink messages, concatenated */
+  vec raw_off;  /* u64 */
+  vec payload;  /* u8 */
+  vec pay_off;  /* u64 (n+1) */
+  vec pay_len;  /* u32 */
+  vec pay_ok;   /* u8 */
+};
+
+#define QSCALE 1099511627776.0 /* 2^40 */
+#define QINV (1.0 / 1099511627776.0)
+
+static inline int64_t q40(float v) {
+  /* |v| is clamped so that 2048-term windows stay inside int64 */
+  if (v > 511.0f) v = 511.0f;
+  if (v < -511.0f) v = -511.0f;
+  return (int64_t)llrint((double)v * QSCALE);
+}
+
+/* gr_fft_filter_ccc(1, taps) == causal linear convolution with zero pre-history
+ * (ofdm_receiver.py~:76,131).  One fmaf chain per output sample, tap order 0..nt-1. */
+static void chan_filter(const ofdm_cfg *cfg, const ofdm_c32 *x, uint64_t n, ofdm_c32 *y) {
+  int nt = (int)cfg->ntaps;
+  enum { BLK = 1024 };
+  float are[BLK], aim[BLK];
+  for (uint64_t b = 0; b < n; b += BLK) {
+    int m = (int)((n - b < BLK) ? (n - b) : BLK);
+    for (int i = 0; i < m; i++) are[i] = aim[i] = 0.0f;
+    for (int k = 0; k < nt; k++) {
+      float h = cfg->taps[k];
+      /* outputs b+i with b+i-k >= 0 */
+      int i0 = 0;
+      if ((uint64_t)k > b) i0 = (int)((uint64_t)k - b);
+      if (i0 >= m) {
+        /* x index negative for the whole block: contributes fmaf(h, 0, acc) = acc */
+        continue;
+      }
+      const ofdm_c32 *xs = x + ((int64_t)b - (int64_t)k); /* valid from i0 */
+      for (int i = i0; i < m; i++) {
+        are[i] = fmaf(h, xs[i].re, are[i]);
+        aim[i] = fmaf(h, xs[i].im, aim[i]);
+      }
+    }
+    for (int i = 0; i < m; i++) y[b + i] = c32(are[i], aim[i]);
+  }
+}
+
+/* ofdm_sync_pn(N, CP) (ofdm_receiver.py~:97-101): delay N/2, conj, multiply, two
+ * N/2 moving sums, |.|^2, square, divide, CP-length moving average, -1.
+ * Outputs u[n] (peak detector input) and P[n] (for complex_to_arg).            */
+static void sync_metric(const ofdm_cfg *cfg, const ofdm_c32 *y, uint64_t n, float *u, ofdm_c32 *P) {
+  int D = (int)cfg->fft_length / 2, CP = (int)cfg->cp_length;
+  float tapcp = (float)(1.0 / (double)CP);
+  int64_t *qpr = (int64_t *)malloc(sizeof(int64_t) * (size_t)D);
+  int64_t *qpi = (int64_t *)malloc(sizeof(int64_t) * (size_t)D);
+  int64_t *qr = (int64_t *)malloc(sizeof(int64_t) * (size_t)D);
+  int64_t *qm = (int64_t *)malloc(sizeof(int64_t) * (size_t)CP);
+  memset(qpr, 0, sizeof(int64_t) * (size_t)D);
+  memset(qpi, 0, sizeof(int64_t) * (size_t)D);
+  memset(qr, 0, sizeof(int64_t) * (size_t)D);
+  memset(qm, 0, sizeof(int64_t) * (size_t)CP);
+  int64_t spr = 0, spi = 0, sr = 0, sm = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    ofdm_c32 a = y[i];
+    ofdm_c32 d = (i >= (uint64_t)D) ? y[i - (uint64_t)D] : c32(0.0f, 0.0f);
+    ofdm_c32 c = cmul_conj(a, d);
+    float e = a.re * a.re + a.im * a.im;
+    int s = (int)(i % (uint64_t)D);
+    int64_t v;
+    v = q40(c.re);
+    spr += v - qpr[s];
+    qpr[s] = v;
+    v = q40(c.im);
+    spi += v - qpi[s];
+    qpi[s] = v;
+    v = q40(e);
+    sr += v - qr[s];
+    qr[s] = v;
+    float pre = (float)((double)spr * QINV);
+    float pim = (float)((double)spi * QINV);
+    float r = (float)((double)sr * QINV);
+    float num = pre * pre + pim * pim;
+    float den = r * r;
+    float m = (den > 0.0f) ? (num / den) : 0.0f;
+    if (!(m <= 1024.0f)) m = 1024.0f;
+    int sc = (int)(i % (uint64_t)CP);
+    v = (int64_t)llrint((double)m * QSCALE);
+    sm += v - qm[sc];
+    qm[sc] = v;
+    float mbar = (float)((double)sm * QINV * (double)tapcp);
+    u[i] = mbar + (-1.0f);
+    P[i] = c32(pre, pim);
+  }
+  free(qpr);
+  free(qpi);
+  free(qr);
+  free(qm);
+}
+
+/* gr_peak_detector_fb(0.20, 0.20, 30, 0.001) over the whole stream as one buffer */
+static void peak_detect(const ofdm_cfg *cfg, const float *u, uint64_t n, vec *peaks) {
+  float rise = cfg->peak_rise, fall = cfg->peak_fall, alpha = cfg->peak_alpha;
+  float one_m_alpha = 1.0f - alpha;
+  float avg = 0.0f, peak_val = -INFINITY;
+  uint64_t peak_ind = 0;
+  int state = 0;
+  uint64_t i = 0;
+  while (i < n) {
+    if (state == 0) {
+      if (u[i] > avg * rise) {
+        state = 1;
+      } else {
+        avg = alpha * u[i] + one_m_alpha * avg;
+        i++;
+      }
+    } else {
+      if (u[i] > peak_val) {
+        peak_val = u[i];
+        peak_ind = i;
+        avg = alpha * u[i] + one_m_alpha * avg;
+        i++;
+      } else if (u[i] > avg * fall) {
+        avg = alpha * u[i] + one_m_alpha * avg;
+        i++;
+      } else {
+        *(uint64_t *)vec_push(peaks, 1) = peak_ind;
+        state = 0;
+        peak_val = -INFINITY;
+      }
+    }
+  }
+  /* a run still open at the end of the stream raises no flag (GR would wait for more input) */
+}
+
+typedef struct {
+  ofdm_c32 pos[OFDM_MAX_ARITY];
+  int arity, nbits, occ, nmap;
+  int map[OFDM_MAX_FFT];
+  ofdm_c32 dfe[OFDM_MAX_FFT];
+  float phase, freq, phase_gain, freq_gain, eq_gain;
+  int state; /* 0 SYNC_SEARCH, 1 HAVE_SYNC, 2 HAVE_HEADER */
+  uint32_t header;
+  int hdr_cnt;
+  unsigned byte_offset, partial_byte, resid, nresid;
+  int packetlen, packetlen_cnt, whitener_offset;
+  uint8_t packet[OFDM_MAX_PKT_LEN + 8];
+  uint8_t bytes_out[OFDM_MAX_FFT]; /* one symbol never makes more bytes than carriers */
+} frame_sink;
+
+static void sink_enter_have_sync(frame_sink *s) {
+  s->state = 1;
+  s->byte_offset = 0;
+  s->partial_byte = 0;
+  s->resid = 0;
+  s->nresid = 0;
+  s->header = 0;
+  s->hdr_cnt = 0;
+  s->phase = 0.0f;
+  s->freq = 0.0f;
+  for (int i = 0; i < s->occ; i++) s->dfe[i] = c32(1.0f, 0.0f);
+}
+
+static unsigned sink_slicer(const frame_sink *s, ofdm_c32 x) {
+  unsigned min_index = 0;
+  ofdm_c32 d = c32(x.re - s->pos[0].re, x.im - s->pos[0].im);
+  float min_dist = cnorm(d);
+  for (int j = 1; j < s->arity; j++) {
+    d = c32(x.re - s->pos[j].re, x.im - s->pos[j].im);
+    float e = cnorm(d);
+    if (e < min_dist) {
+      min_dist = e;
+      min_index = (unsigned)j;
+    }
+  }
+  return min_index; /* sym_value_out = range(arity), ofdm.py:240 */
+}
+
+/* digital_ofdm_frame_sink::demapper */
+static unsigned sink_demapper(frame_sink *s, const ofdm_c32 *in, uint8_t *out, ofdm_c32 *derot) {
+  unsigned i = 0, bytes_produced = 0;
+  ofdm_c32 carrier = c32(cosf(s->phase), sinf(s->phase));
+  ofdm_c32 acc = c32(0.0f, 0.0f);
+  unsigned nmap = (unsigned)s->nmap, nb = (unsigned)s->nbits;
+  if (derot) memset(derot, 0, sizeof(ofdm_c32) * (size_t)s->occ);
+  while (i < nmap) {
+    if (s->nresid > 0) {
+      s->partial_byte |= s->resid;
+      s->byte_offset += s->nresid;
+      s->nresid = 0;
+      s->resid = 0;
+    }
+    while (s->byte_offset < 8 && i < nmap) {
+      ofdm_c32 sigrot = cmul(cmul(in[s->map[i]], carrier), s->dfe[i]);
+      if (derot) derot[i] = sigrot;
+      unsigned bits = sink_slicer(s, sigrot);
+      ofdm_c32 closest = s->pos[bits];
+      ofdm_c32 e = cmul_conj(sigrot, closest);
+      acc.re = acc.re + e.re;
+      acc.im = acc.im + e.im;
+      if (cnorm(sigrot) > 0.001f) {
+        ofdm_c32 q = cdiv(closest, sigrot);
+        s->dfe[i].re = s->dfe[i].re + s->eq_gain * (q.re - s->dfe[i].re);
+        s->dfe[i].im = s->dfe[i].im + s->eq_gain * (q.im - s->dfe[i].im);
+      }
+      i++;
+      if (8 - s->byte_offset >= nb) {
+        s->partial_byte |= bits << s->byte_offset;
+        s->byte_offset += nb;
+      } else {
+        s->nresid = nb - (8 - s->byte_offset);
+        unsigned mask = (1u << (8 - s->byte_offset)) - 1u;
+        s->partial_byte |= (bits & mask) << s->byte_offset;
+        s->resid = bits >> (8 - s->byte_offset);
+        s->byte_offset += nb - s->nresid;
+      }
+    }
+    if (s->byte_offset == 8) {
+      out[bytes_produced++] = (uint8_t)s->partial_byte;
+      s->byte_offset = 0;
+      s->partial_byte = 0;
+    }
+  }
+  float angle = atan2f(acc.im, acc.re);
+  s->freq = s->freq - s->freq_gain * angle;
+  s->phase = s->phase + s->freq - s->phase_gain * angle;
+  if (s->phase >= 6.28318530717958647692f) s->phase -= 6.28318530717958647692f;
+  if (s->phase < 0.0f) s->phase += 6.28318530717958647692f;
+  return bytes_produced;
+}
+
+static void rx_post_message(orc_rx_result *r, const ofdm_cfg *cfg, const uint8_t *msg, int len) {
+  *(uint64_t *)vec_push(&r->raw_off, 1) = r->raw.n;
+  memcpy(vec_push(&r->raw, (size_t)len), msg, (size_t)len);
+  /* _queue_watcher_thread.run: unmake_packet(msg.to_string()) (ofdm.py:300-305) */
+  uint8_t pay[OFDM_MASK_LEN];
+  uint32_t plen = 0;
+  int ok = 0;
+  orc_unmake_packet(cfg, msg, (uint32_t)len, pay, &plen, &ok);
+  *(uint64_t *)vec_push(&r->pay_off, 1) = r->payload.n;
+  memcpy(vec_push(&r->payload, plen), pay, plen);
+  *(uint32_t *)vec_push(&r->pay_len, 1) = plen;
+  *(uint8_t *)vec_push(&r->pay_ok, 1) = (uint8_t)ok;
+  r->st.packets++;
+  if (ok) r->st.crc_ok++;
+}
+
+#define YAT(ix) (((ix) >= 0 && (ix) < N) ? Y[(ix)] : c32(0.0f, 0.0f))
+
+orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint32_t tap_mask) {
+  int N = (int)cfg->fft_length, CP = (int)cfg->cp_length, occ = (int)cfg->occupied_tones;
+  int L = N + CP;
+  orc_rx_result *r = (orc_rx_result *)calloc(1, sizeof(*r));
+  r->tap_mask = tap_mask;
+  r->N = N;
+  r->occ = occ;
+  vec_init(&r->y, sizeof(ofdm_c32));
+  vec_init(&r->metric, sizeof(float));
+  vec_init(&r->peaks, sizeof(uint64_t));
+  vec_init(&r->angles, sizeof(float));
+  vec_init(&r->frames, sizeof(uint64_t));
+  vec_init(&r->fft, sizeof(ofdm_c32));
+  vec_init(&r->acq, sizeof(ofdm_c32));
+  vec_init(&r->sink, sizeof(ofdm_c32));
+  vec_init(&r->raw, 1);
+  vec_init(&r->raw_off, sizeof(uint64_t));
+  vec_init(&r->payload, 1);
+  vec_init(&r->pay_off, sizeof(uint64_t));
+  vec_init(&r->pay_len, sizeof(uint32_t));
+  vec_init(&r->pay_ok, 1);
+  r->st.samples = n;
+  if (n == 0) return r;
+
+  /* --- chan_filt ------------------------------------------------------- */
+  ofdm_c32 *y = (ofdm_c32 *)vec_push(&r->y, n);
+  chan_filter(cfg, iq, n, y);
+
+  /* --- ofdm_sync_pn ---------------------------------------------------- */
+  float *u = (float *)vec_push(&r->metric, n);
+  ofdm_c32 *P = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * n);
+  sync_metric(cfg, y, n, u, P);
+  peak_detect(cfg, u, n, &r->peaks);
+  uint64_t npk = r->peaks.n;
+  const uint64_t *pk = (const uint64_t *)r->peaks.p;
+  r->st.peaks = npk;
+
+  /* gr_sample_and_hold_ff(complex_to_arg(P), timing) + gr_frequency_modulator_fc(-2/N)
+   * (ofdm_receiver.py~:98,123,133): closed form, float64 phase.  Phi[j] = phase of the
+   * last sample before flag j takes effect; for pk[j] <= n < pk[j+1]:
+   * phi[n] = Phi[j] + step[j]*(n - pk[j] + 1).                                   */
+  float sens = (float)(-2.0 / (double)N);
+  float *ang = (float *)vec_push(&r->angles, npk);
+  double *Phi = (double *)malloc(sizeof(double) * (npk + 1));
+  double *step = (double *)malloc(sizeof(double) * (npk + 1));
+  Phi[0] = 0.0;
+  for (uint64_t j = 0; j < npk; j++) {
+    ang[j] = atan2f(P[pk[j]].im, P[pk[j]].re);
+    step[j] = (double)(sens * ang[j]);
+    if (j + 1 < npk) Phi[j + 1] = Phi[j] + step[j] * (double)(pk[j + 1] - pk[j]);
+  }
+  free(P);
+
+  /* --- per-symbol machinery -------------------------------------------- */
+  int zl = (N - occ + 1) / 2;
+  int shift = (int)cfg->max_fft_shift_len;
+  fft_plan plan;
+  fft_plan_init(&plan, N);
+  ofdm_c32 *win = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)N);
+  ofdm_c32 *Y = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)N);
+  ofdm_c32 *acq = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)occ);
+  ofdm_c32 *hinv = (ofdm_c32 *)calloc((size_t)occ, sizeof(ofdm_c32));
+  float *kd = (float *)calloc((size_t)occ, sizeof(float));
+  float *sd = (float *)calloc((size_t)N, sizeof(float));
+  ofdm_c32 *derot = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)occ);
+  /* digital_ofdm_frame_acquisition ctor: known_phase_diff */
+  for (int i = 0; i + 2 < occ; i += 2) {
+    ofdm_c32 a = cfg->known_symbol[i], b = cfg->known_symbol[i + 2];
+    kd[i] = cnorm(c32(a.re - b.re, a.im - b.im));
+  }
+  int coarse = 0;
+  unsigned phase_count = 1;
+
+  frame_sink *sk = (frame_sink *)calloc(1, sizeof(frame_sink));
+  sk->arity = (int)cfg->arity;
+  sk->nbits = orc_nbits(cfg);
+  sk->occ = occ;
+  memcpy(sk->pos, cfg->constellation, sizeof(ofdm_c32) * cfg->arity);
+  sk->nmap = orc_carrier_map(occ, occ, sk->map, OFDM_MAX_FFT);
+  sk->phase_gain = cfg->phase_gain;
+  sk->freq_gain = cfg->freq_gain;
+  sk->eq_gain = cfg->eq_gain;
+  for (int i = 0; i < occ; i++) sk->dfe[i] = c32(1.0f, 0.0f);
+  sk->state = 0;
+  if (sk->nmap < 0) sk->nmap = 0;
+
+  /* --- digital_ofdm_sampler(N, N+CP, timeout) automaton (ofdm_receiver.py~:125) --- */
+  enum { ST_NO_SIG, ST_PREAMBLE, ST_FRAME };
+  int sstate = ST_NO_SIG;
+  int64_t timeout = 0;
+  uint64_t base = 0;
+  uint64_t next_pk = 0;     /* first peak with index >= scan start */
+  uint64_t cur_frame_data = 0;
+  while (base + (uint64_t)L + (uint64_t)N < n) { /* the scan touches trigger[base+L+N] */
+    /* search trigger[base+N .. base+L+N] unless already in PREAMBLE */
+    uint64_t lo = base + (uint64_t)N, hi = base + (uint64_t)L + (uint64_t)N;
+    while (next_pk < npk && pk[next_pk] < lo) next_pk++;
+    int found = (next_pk < npk && pk[next_pk] <= hi);
+    uint64_t sym_start;
+    int flag;
+    if (found) {
+      uint64_t p = pk[next_pk];
+      sstate = ST_PREAMBLE;
+      sym_start = p - (uint64_t)N + 1;
+      flag = 1;
+      timeout = (int64_t)cfg->sampler_timeout;
+      sstate = ST_FRAME;
+      base = sym_start; /* consume_each(index - N + 1) */
+      next_pk++;
+      uint64_t *fr = (uint64_t *)vec_push(&r->frames, 2);
+      fr[0] = p;
+      fr[1] = 0;
+      cur_frame_data = r->frames.n - 1;
+      r->st.frames++;
+    } else if (sstate == ST_FRAME) {
+      sym_start = base + (uint64_t)L;
+      flag = 0;
+      if (timeout-- == 0) sstate = ST_NO_SIG;
+      base += (uint64_t)L;
+      ((uint64_t *)r->frames.p)[cur_frame_data]++;
+    } else {
+      base += (uint64_t)L + 1; /* consume_each(index - N), index ran to L+N+1 */
+      continue;
+    }
+    r->st.symbols++;
+
+    /* --- sigmix: chan_filt * nco over this symbol's N samples --------------- */
+    {
+      /* cnt = number of flags at or before the sample (binary search at the symbol start) */
+      uint64_t lo2 = 0, hi2 = npk;
+      while (lo2 < hi2) {
+        uint64_t mid = (lo2 + hi2) / 2;
+        if (pk[mid] <= sym_start)
+          lo2 = mid + 1;
+        else
+          hi2 = mid;
+      }
+      uint64_t cnt = lo2;
+      for (int m = 0; m < N; m++) {
+        uint64_t idx = sym_start + (uint64_t)m;
+        while (cnt < npk && pk[cnt] <= idx) cnt++;
+        double ph = 0.0;
+        if (cnt > 0) {
+          uint64_t j = cnt - 1;
+          ph = Phi[j] + step[j] * (double)(idx - pk[j] + 1);
+        }
+        ph = ph - 2.0 * M_PI * floor(ph / (2.0 * M_PI) + 0.5);
+        ofdm_c32 rot = c32((float)cos(ph), (float)sin(ph));
+        win[m] = cmul(y[idx], rot);
+      }
+    }
+
+    /* --- gr.fft_vcc(N, True, [1]*N, True): forward DFT, output halves swapped -- */
+    fft_exec(&plan, win, 0);
+    for (int k = 0; k < N; k++) Y[k] = win[(k + N / 2) % N];
+    if (tap_mask & (1u << OFDM_TAP_RX_FFT)) memcpy(vec_push(&r->fft, (size_t)N), Y, sizeof(ofdm_c32) * (size_t)N);
+
+    /* --- digital_ofdm_frame_acquisition(occ, N, CP, ks[0], 4) ---------------- */
+    if (flag) {
+      phase_count = 1;
+      /* correlate() */
+      for (int i = 0; i < N; i++) sd[i] = 0.0f;
+      for (int i = 0; i < N - 2; i++) sd[i] = cnorm(c32(Y[i].re - Y[i + 2].re, Y[i].im - Y[i + 2].im));
+      int index = 0;
+      float mx = 0.0f;
+      for (int i = zl - shift; i < zl + shift; i++) {
+        float sum = 0.0f;
+        for (int j = 0; j < occ; j++) {
+          int q = i + j;
+          float s2 = (q >= 0 && q < N) ? sd[q] : 0.0f;
+          sum = sum + kd[j] * s2;
+        }
+        if (sum > mx) {
+          mx = sum;
+          index = i;
+        }
+      }
+      coarse = index - zl;
+      /* calculate_equalizer() */
+      {
+        double a = -2.0 * M_PI * (double)coarse * (double)CP / (double)N * 1.0;
+        float af = (float)a;
+        ofdm_c32 comp = c32(cosf(af), sinf(af));
+        hinv[0] = cdiv(cfg->known_symbol[0], cmul(comp, YAT(zl + coarse)));
+        for (int i = 2; i < occ; i += 2) {
+          hinv[i] = cdiv(cfg->known_symbol[i], cmul(comp, YAT(i + zl + coarse)));
+          hinv[i - 1] = c32((hinv[i].re + hinv[i - 2].re) / 2.0f, (hinv[i].im + hinv[i - 2].im) / 2.0f);
+        }
+        if (!(occ & 1)) hinv[occ - 1] = hinv[occ - 2];
+      }
+    }
+    {
+      double a = -2.0 * M_PI * (double)coarse * (double)CP / (double)N * (double)phase_count;
+      float af = (float)a;
+      ofdm_c32 comp = c32(cosf(af), sinf(af));
+      for (int i = 0; i < occ; i++) acq[i] = cmul(cmul(hinv[i], comp), YAT(i + zl + coarse));
+      phase_count++;
+      if (phase_count == 1000) phase_count = 1; /* MAX_NUM_SYMBOLS */
+    }
+    if (tap_mask & (1u << OFDM_TAP_RX_ACQ)) memcpy(vec_push(&r->acq, (size_t)occ), acq, sizeof(ofdm_c32) * (size_t)occ);
+
+    /* --- digital_ofdm_frame_sink::work (ofdm.py:240-247) --------------------- */
+    if (sk->state == 0) {
+      if (flag) sink_enter_have_sync(sk);
+    } else if (sk->state == 1) {
+      unsigned bytes = sink_demapper(sk, acq, sk->bytes_out, derot);
+      if (flag) r->st.chained_frames++;
+      if (tap_mask & (1u << OFDM_TAP_RX_SINK)) memcpy(vec_push(&r->sink, (size_t)occ), derot, sizeof(ofdm_c32) * (size_t)occ);
+      unsigned j = 0;
+      while (j < bytes) {
+        sk->header = (sk->header << 8) | (uint32_t)sk->bytes_out[j];
+        j++;
+        if (++sk->hdr_cnt == 4) {
+          if (((sk->header >> 16) ^ (sk->header & 0xFFFF)) == 0) {
+            r->st.headers_ok++;
+            sk->state = 2;
+            sk->packetlen = (int)((sk->header >> 16) & 0x0FFF);
+            sk->whitener_offset = (int)((sk->header >> 28) & 0xF);
+            sk->packetlen_cnt = 0;
+            while (j < bytes && sk->packetlen_cnt < sk->packetlen) sk->packet[sk->packetlen_cnt++] = sk->bytes_out[j++];
+            if (sk->packetlen_cnt == sk->packetlen) {
+              rx_post_message(r, cfg, sk->packet, sk->packetlen);
+              sk->state = 0;
+            }
+          } else {
+            sk->state = 0; /* bad header */
+          }
+        }
+      }
+    } else {
+      unsigned bytes = sink_demapper(sk, acq, sk->bytes_out, derot);
+      if (flag) r->st.chained_frames++;
+      if (tap_mask & (1u << OFDM_TAP_RX_SINK)) memcpy(vec_push(&r->sink, (size_t)occ), derot, sizeof(ofdm_c32) * (size_t)occ);
+      unsigned j = 0;
+      while (j < bytes) {
+        sk->packet[sk->packetlen_cnt++] = sk->bytes_out[j++];
+        if (sk->packetlen_cnt == sk->packetlen) {
+          rx_post_message(r, cfg, sk->packet, sk->packetlen);
+          sk->state = 0;
+          break;
+        }
+      }
+    }
+  }
+  *(uint64_t *)vec_push(&r->raw_off, 1) = r->raw.n;
+  *(uint64_t *)vec_push(&r->pay_off, 1) = r->payload.n;
+
+  free(sk);
+  free(derot);
+  free(sd);
+  free(kd);
+  free(hinv);
+  free(acq);
+  free(Y);
+  free(win);
+  fft_plan_free(&plan);
+  free(step);
+  free(Phi);
+  if (!(tap_mask & (1u << OFDM_TAP_RX_CHAN_FILT))) vec_free(&r->y);
+  if (!(tap_mask & (1u << OFDM_TAP_RX_METRIC))) vec_free(&r->metric);
+  return r;
+}
+
+uint64_t orc_rx_tap(const orc_rx_result *r, int tap, void *out, uint64_t cap_bytes) {
+  const vec *v = NULL;
+  switch (tap) {
+    case OFDM_TAP_RX_CHAN_FILT: v = &r->y; break;
+    case OFDM_TAP_RX_METRIC: v = &r->metric; break;
+    case OFDM_TAP_RX_PEAKS: v = &r->peaks; break;
+    case OFDM_TAP_RX_ANGLES: v = &r->angles; break;
+    case OFDM_TAP_RX_FRAMES: v = &r->frames; break;
+    case OFDM_TAP_RX_FFT: v = &r->fft; break;
+    case OFDM_TAP_RX_ACQ: v = &r->acq; break;
+    case OFDM_TAP_RX_SINK: v = &r->sink; break;
+    case OFDM_TAP_RX_PACKETS: v = &r->raw; break;
+    default: return 0;
+  }
+  uint64_t nb = (uint64_t)v->n * v->esz;
+  if (out && cap_bytes >= nb && nb) memcpy(out, v->p, nb);
+  return nb;
+}
+
+int orc_rx_npackets(const orc_rx_result *r) { return (int)r->pay_len.n; }
+uint64_t orc_rx_payload_bytes(const orc_rx_result *r) { return r->payload.n; }
+
+int orc_rx_packets(const orc_rx_result *r, uint8_t *payload_out, uint64_t cap, uint64_t *off, uint32_t *len,
+                   uint8_t *ok, int max_pkts) {
+  int np = (int)r->pay_len.n;
+  if (np > max_pkts || r->payload.n > cap) return OFDM_E_CAPACITY;
+  if (r->payload.n) memcpy(payload_out, r->payload.p, r->payload.n);
+  memcpy(off, r->pay_off.p, sizeof(uint64_t) * (size_t)(np + 1));
+  if (np) {
+    memcpy(len, r->pay_len.p, sizeof(uint32_t) * (size_t)np);
+    memcpy(ok, r->pay_ok.p, (size_t)np);
+  }
+  return np;
+}
+
+void orc_rx_stats(const orc_rx_result *r, ofdm_stats *st) { *st = r->st; }
+
+void orc_rx_free(orc_rx_result *r) {
+  if (!r) return;
+  vec_free(&r->y);
+  vec_free(&r->metric);
+  vec_free(&r->peaks);
+  vec_free(&r->angles);
+  vec_free(&r->frames);
+  vec_free(&r->fft);
+  vec_free(&r->acq);
+  vec_free(&r->sink);
+  vec_free(&r->raw);
+  vec_free(&r->raw_off);
+  vec_free(&r->payload);
+  vec_free(&r->pay_off);
+  vec_free(&r->pay_len);
+  vec_free(&r->pay_ok);
+  free(r);
+}
