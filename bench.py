@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- OFDM symbols/s, TX + loopback RX, on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic input on every rank:
+`packets` payloads (benchmark_ofdm_tx layout, 1026 B) -> make_packet -> map -> IFFT -> CP
+(+ AWGN at 30 dB fused into the store) -> channel filter -> Schmidl-Cox sync -> CP strip ->
+FFT -> equalise -> demap -> deframe/CRC, at BASELINE config 2 (N_fft=512, occ=200, CP=128,
+QPSK).  Payload bytes are resident in HBM before the timed region and the recovered payloads
+stay in HBM (nothing crosses PCIe inside it).  Each rank owns an independent IQ stream
+(stream id = rank): weak scaling, no data-path collective; RCCL only reduces the packet
+counters and the elapsed time at the end.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_payload_blob(npkt, size, stream_id):
+    """payload = !H pktno | !H 0 | data (benchmark_ofdm_tx.py:117); data from PCG64(0x0FD30000 + stream)."""
+    rng = np.random.Generator(np.random.PCG64(0x0FD30000 + stream_id))
+    blob = rng.integers(0, 256, size=(npkt, size), dtype=np.uint8)
+    pktno = np.arange(npkt, dtype=np.uint32) & 0xFFFF
+    blob[:, 0] = (pktno >> 8).astype(np.uint8)
+    blob[:, 1] = (pktno & 0xFF).astype(np.uint8)
+    blob[:, 2] = 0
+    blob[:, 3] = 0
+    return np.ascontiguousarray(blob.reshape(-1))
+
+
+def cpu_baseline(cfg, sigma, lead, tail, size, npkt):
+    """The oracle (a single-threaded C port of the reference flow graph) on a bounded sample of the
+    same workload, timed on this host's cores.  A reported baseline, not the optimisation target."""
+    from oracle import oracle as orc
+    blob = make_payload_blob(npkt, size, 0)
+    pay = [blob[i * size:(i + 1) * size].tobytes() for i in range(npkt)]
+    orc.lib()
+    t0 = time.perf_counter()
+    iq = orc.tx(cfg, pay, lead=lead, tail=tail)
+    orc.channel(iq, sigma=sigma, seed=0xC0FFEE, stream_id=0)
+    r = orc.rx(cfg, iq)
+    dt = time.perf_counter() - t0
+    nsym = (len(iq) - lead - tail) // (cfg.fft_length + cfg.cp_length)
+    ok = sum(1 for o, _ in r.packets if o)
+    return {"value": nsym / dt, "unit": "OFDM symbols/s", "cores": 1, "kind": "port",
+            "sample": "%d packets (%d symbols) of the same workload through oracle/ofdm_oracle.c, TX+AWGN+RX, "
+                      "1 thread, %.1f s; CRC pass %d/%d" % (npkt, nsym, dt, ok, npkt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--packets", type=int, default=65536, help="packets per stream per step")
+    ap.add_argument("--size", type=int, default=1026, help="payload bytes (4-byte prefix + 1022 data)")
+    ap.add_argument("--snr", type=float, default=30.0)
+    ap.add_argument("--cpu-packets", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    from ofdm_uhd_amd import _abi, config, engine, options, parallel
+
+    rank, local_rank, world = parallel.init_process_group()
+    if world != max(args.gpus, 1) and rank == 0:
+        sys.stderr.write("warning: --gpus %d but WORLD_SIZE %d\n" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine is the only implementation)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    N, occ, CP, mod = 512, 200, 128, "qpsk"
+    opt = options.default_options(modulation=mod, fft_length=N, occupied_tones=occ, cp_length=CP, tx_amplitude=0.25)
+    cfg = config.make_cfg(opt, device_ptrs=True, device_id=local_rank)
+    eng = engine.Engine(cfg=cfg)
+    L = N + CP
+    P, size = args.packets, args.size
+    stream_id = rank
+    ncar = len(config.carrier_map(occ, N))
+    # mean in-packet power: ncar unit-power carriers through IFFT/sqrt(N), amplitude 0.25, |QPSK point|^2 = 0.9997
+    psig = ncar / float(N) * 0.25 ** 2 * abs(config.rotated_constellation(mod)[0]) ** 2
+    sigma = float(np.sqrt(psig / 10 ** (args.snr / 10.0)))
+    lead, tail = 2 * N, L + 2 * N
+    eng.set_channel(sigma=sigma, cfo=0.0, seed=0xC0FFEE, stream_id=stream_id, lead=lead, tail=tail)
+
+    blob = make_payload_blob(P, size, stream_id)
+    offs = (np.arange(P, dtype=np.uint64) * np.uint64(size))
+    lens = np.full(P, size, np.uint32)
+    nsym, nsamp = eng.tx_frame_count(lens)
+    d_blob = torch.from_numpy(blob).to(dev)                       # resident before the timed region
+    d_iq = torch.empty(nsamp * 2, dtype=torch.float32, device=dev)
+    d_out = torch.empty(P * size + 4096, dtype=torch.uint8, device=dev)
+    max_pkts = P + 1024
+
+    def step():
+        n = eng.tx_device(d_blob.data_ptr(), offs, lens, d_iq.data_ptr(), nsamp)
+        tx_stats = dict(eng.last_stats)
+        npk, off, ln, ok = eng.rx_device(d_iq.data_ptr(), n, d_out.data_ptr(), d_out.numel(), max_pkts)
+        return tx_stats, dict(eng.last_stats), npk, off, ln, ok
+
+    for _ in range(args.warmup):
+        step()
+    eng.prof_enable(True)
+    eng.prof_reset()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot = {"symbols": 0, "packets": 0, "crc_ok": 0, "samples": 0, "frames": 0, "peaks": 0}
+    for _ in range(args.steps):
+        tx_stats, rx_stats, npk, off, ln, ok = step()
+        tot["symbols"] += tx_stats["symbols"]
+        tot["samples"] += rx_stats["samples"]
+        tot["packets"] += npk
+        tot["crc_ok"] += int(ok.sum())
+        tot["frames"] += rx_stats["frames"]
+        tot["peaks"] += rx_stats["peaks"]
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.prof()
+    eng.prof_enable(False)
+
+    # correctness of the last step: every payload back bit-exact, in order
+    bit_exact = bool(npk == P and bool(ok.all()) and bool((ln == size).all()) and
+                     torch.equal(d_out[:P * size], d_blob))
+    elapsed = parallel.reduce_max(elapsed, device=dev)
+    g = parallel.reduce_counters(tot, device=dev)
+    all_exact = parallel.reduce_counters({"packets": int(bit_exact)}, device=dev)["packets"] == world
+
+    if rank == 0:
+        sym_per_s = g["symbols"] / elapsed
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        # dominant kernel by HIP-event time (events recorded on the engine's own stream)
+        kern = max(prof.items(), key=lambda kv: kv[1][0])
+        kname, (kms, klaunch) = kern
+        # algorithmic bytes of ONE launch of that kernel (DESIGN.md "Roofline accounting"):
+        #   k_sync / k_rx_demod : the compulsory read of the received stream, (N+CP)*8 B per symbol
+        #   k_tx_mod            : the compulsory write of the stream + the packet bits in
+        per_symbol = {"k_sync": L * 8.0, "k_rx_demod": L * 8.0 + ncar * 2 / 8.0,
+                      "k_tx_mod": L * 8.0 + ncar * 2 / 8.0}.get(kname, L * 8.0)
+        launch_bytes = per_symbol * nsym
+        avg_s = (kms / max(klaunch, 1)) * 1e-3
+        achieved = launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        path_bytes = 2 * L * 8.0 + 2 * ncar * 2 / 8.0               # 10 339 B per symbol at C2
+        out = {
+            "metric": "OFDM symbols/sec (TX+loopback RX) @ N_fft=512; packet CRC pass rate",
+            "value": sym_per_s,
+            "unit": "OFDM symbols/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "N_fft=512, occ=200, QPSK, CP=128, synthetic AWGN channel (BASELINE configs[1])",
+                       "packets_per_stream_per_step": P, "payload_bytes": size, "symbols_per_packet": nsym // P,
+                       "snr_db": args.snr, "streams": world, "parallelism": "independent streams, 1 per GPU"},
+            "crc_pass_rate": g["crc_ok"] / float(max(world * P * args.steps, 1)),
+            "packets_bit_exact": all_exact,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kname,
+                         "kernel_avg_ms": kms / max(klaunch, 1), "algorithmic_bytes_per_launch": launch_bytes,
+                         "path_achieved": sym_per_s / world * path_bytes / 1e9,
+                         "path_frac": sym_per_s / world * path_bytes / 1e9 / HBM_PEAK_GBPS},
+            "kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
+        }
+        if args.cpu_packets > 0:
+            cfg_host = config.make_cfg(opt)
+            out["cpu_baseline"] = cpu_baseline(cfg_host, sigma, lead, tail, size, args.cpu_packets)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+if __name__ == "__main__":
+    main()

@@ -559,12 +559,12 @@ __global__ void __launch_bounds__(256) k_raw_len(DeframeParams q, uint64_t* __re
 // receive-side workspaces
 // ------------------------------------------------------------------------------------
 struct RxState {
-  DevBuf x_stage, y, metric, tile_B, tile_np, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
+  DevBuf x_stage, y, metric, tile_B, tile_np, tile_first, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
       partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
       out_payload, out_off, out_len, out_ok, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
   void release() {
-    DevBuf* all[] = {&x_stage, &y,      &metric,  &tile_B,   &tile_np,  &tile_pieces, &avg_in,     &cand_u,
+    DevBuf* all[] = {&x_stage, &y,      &metric,  &tile_B,   &tile_np,  &tile_first, &tile_pieces, &avg_in,     &cand_u,
                      &cand_P,  &counters, &counts, &offsets,  &partial,  &peaks,       &peak_P,     &angle,
                      &step,    &inc,    &Phi,     &K,        &nsym,     &sym_base,    &res,        &raw,
                      &invalid, &chain_list, &key, &pos,      &out_payload, &out_off,  &out_len,    &out_ok,

@@ -22,7 +22,6 @@
 #define SYNC_THREADS 256
 #define SYNC_V 8                            // consecutive samples per thread
 #define SYNC_TILE (SYNC_THREADS * SYNC_V)   // 2048 samples per tile
-#define SYNC_MAXP 4                         // candidate pieces recorded per tile
 
 struct SyncPiece {
   uint64_t start;    // absolute sample index of the first candidate of the piece
@@ -49,8 +48,11 @@ struct SyncParams {
   float* metric_tap;  // optional [nsamples]
   // outputs
   double* tile_B;          // [ntiles] zero-init running average over the tile
-  uint32_t* tile_npieces;  // [ntiles]
-  SyncPiece* tile_pieces;  // [ntiles][SYNC_MAXP]
+  uint32_t* tile_npieces;  // [ntiles] candidate pieces of the tile ...
+  uint64_t* tile_first;    // [ntiles] ... stored at pieces[tile_first .. +tile_npieces)
+  SyncPiece* pieces;       // [piece_cap]
+  uint64_t piece_cap;
+  unsigned long long* piece_count;  // device counter
   float* cand_u;           // [cand_cap]
   c32* cand_P;             // [cand_cap]
   uint64_t cand_cap;
@@ -91,8 +93,7 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
   double* sc_f64 = reinterpret_cast<double*>(misc + 128);      // 2 * 5 entries
   int* sc_i32 = reinterpret_cast<int*>(misc + 256);            // 5 entries
   unsigned char* cm = misc + 320;                               // 256 candidate masks
-  SyncPiece* lp_pieces = reinterpret_cast<SyncPiece*>(misc + 576);  // SYNC_MAXP * 32 B
-  unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 576 + SYNC_MAXP * sizeof(SyncPiece));
+  unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 576);  // 2 broadcast words
 
   const uint64_t seg = blockIdx.x;
   const uint64_t tile_own0 = seg * (uint64_t)p.tiles_per_seg;
@@ -355,12 +356,16 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
         const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
         if (tid == 0) {
           unsigned long long basev = atomicAdd(p.cand_count, (unsigned long long)ncand);
+          unsigned long long basep = atomicAdd(p.piece_count, (unsigned long long)npieces);
           bc[0] = basev;
-          if (basev + (unsigned long long)ncand > p.cand_cap || npieces > SYNC_MAXP) atomicOr(p.overflow, 1u);
+          bc[1] = basep;
+          if (basev + (unsigned long long)ncand > p.cand_cap || basep + (unsigned long long)npieces > p.piece_cap)
+            atomicOr(p.overflow, 1u);
         }
         __syncthreads();
-        const unsigned long long basev = bc[0];
-        const bool fits = (basev + (unsigned long long)ncand <= p.cand_cap) && npieces <= SYNC_MAXP;
+        const unsigned long long basev = bc[0], basep = bc[1];
+        const bool fits = (basev + (unsigned long long)ncand <= p.cand_cap) &&
+                          (basep + (unsigned long long)npieces <= p.piece_cap);
         if (fits) {
           double a_loc = pre.b;  // zero-init average just before this thread's first sample
           int so = nstart_before, co = ncand_before;
@@ -368,9 +373,10 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
           for (int j = 0; j < SYNC_V; j++) {
             const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
             if ((startmask >> j) & 1u) {
-              lp_pieces[so].start = n;
-              lp_pieces[so].val_off = basev + (unsigned long long)co;
-              lp_pieces[so].bloc = a_loc;
+              SyncPiece* pc = p.pieces + basep + so;
+              pc->start = n;
+              pc->val_off = basev + (unsigned long long)co;
+              pc->bloc = a_loc;
               so++;
             }
             if ((cmask >> j) & 1u) {
@@ -378,13 +384,14 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
               p.cand_P[basev + co] = Pv[j];
               co++;
             }
-            if ((endmask >> j) & 1u) lp_pieces[so - 1].end = n;
+            if ((endmask >> j) & 1u) p.pieces[basep + so - 1].end = n;
             if (j < nv) a_loc = (double)p.alpha * (double)u[j] + p.decay * a_loc;
           }
         }
-        __syncthreads();
-        if (tid < SYNC_MAXP && fits && tid < npieces) p.tile_pieces[tile * SYNC_MAXP + tid] = lp_pieces[tid];
-        if (tid == 0) p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
+        if (tid == 0) {
+          p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
+          p.tile_first[tile] = basep;
+        }
       }
     }
     __syncthreads();
@@ -460,19 +467,20 @@ __global__ void __launch_bounds__(256) k_avg_carry(const double* __restrict__ ti
 }
 
 // ---------------------------------------------------------------------------------
-// gr_peak_detector_fb on one candidate interval (possibly spanning several tiles).
-// One thread per (tile, slot); only piece heads do work.
+// gr_peak_detector_fb on the candidate intervals.  One thread per tile walks the intervals
+// that START in its tile (an interval may run on through following tiles).
 // ---------------------------------------------------------------------------------
 struct PeakParams {
   uint64_t ntiles, nsamples;
   float rise, fall, alpha;
   double decay;
   const uint32_t* tile_npieces;
-  const SyncPiece* tile_pieces;
+  const uint64_t* tile_first;
+  const SyncPiece* pieces;
   const double* avg_in;
   const float* cand_u;
   const c32* cand_P;
-  uint32_t* counts;         // [ntiles*SYNC_MAXP]
+  uint32_t* counts;         // [ntiles] flags raised by intervals starting in the tile
   const uint32_t* offsets;  // exclusive scan of counts (write pass)
   uint64_t* peaks;          // [npeaks]
   c32* peak_P;              // [npeaks]
@@ -480,88 +488,83 @@ struct PeakParams {
 
 template <bool WRITE>
 __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
-  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= p.ntiles * SYNC_MAXP) return;
-  uint64_t g = id / SYNC_MAXP;
-  uint32_t slot = (uint32_t)(id % SYNC_MAXP);
-  if (slot >= p.tile_npieces[g]) {
-    if (!WRITE) p.counts[id] = 0;
-    return;
-  }
-  SyncPiece pc = p.tile_pieces[g * SYNC_MAXP + slot];
-  // a piece that starts on the tile's first sample continues the previous tile's last piece
-  if (slot == 0 && g > 0 && pc.start == g * (uint64_t)SYNC_TILE) {
-    const uint32_t np = p.tile_npieces[g - 1];
-    if (np > 0 && p.tile_pieces[(g - 1) * SYNC_MAXP + np - 1].end + 1 == pc.start) {
-      if (!WRITE) p.counts[id] = 0;
-      return;
-    }
-  }
-  const float one_m_alpha = 1.0f - p.alpha;
-  float avg = (float)(p.avg_in[g] * pow(p.decay, (double)(pc.start - g * (uint64_t)SYNC_TILE)) + pc.bloc);
-  int state = 0;
-  float peak_val = -INFINITY;
-  uint64_t peak_ind = 0;
-  c32 peak_P = mk(0.f, 0.f);
+  const uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g0 >= p.ntiles) return;
+  const uint32_t np0 = p.tile_npieces[g0];
   uint32_t nflag = 0;
-  const uint32_t wbase = WRITE ? p.offsets[id] : 0;
-  bool open_at_stream_end = false;
-  for (;;) {
-    const uint64_t len = pc.end - pc.start + 1;
-    for (uint64_t k = 0; k < len; k++) {
-      const float u = p.cand_u[pc.val_off + k];
-      const uint64_t i = pc.start + k;
-      for (;;) {
-        if (state == 0) {
-          if (u > avg * p.rise) {
-            state = 1;
-            continue;
+  const uint32_t wbase = WRITE ? p.offsets[g0] : 0;
+  const float one_m_alpha = 1.0f - p.alpha;
+  for (uint32_t slot = 0; slot < np0; slot++) {
+    uint64_t g = g0;
+    SyncPiece pc = p.pieces[p.tile_first[g] + slot];
+    // a piece that starts on the tile's first sample continues the previous tile's last piece
+    if (slot == 0 && g > 0 && pc.start == g * (uint64_t)SYNC_TILE) {
+      const uint32_t npp = p.tile_npieces[g - 1];
+      if (npp > 0 && p.pieces[p.tile_first[g - 1] + npp - 1].end + 1 == pc.start) continue;
+    }
+    float avg = (float)(p.avg_in[g] * pow(p.decay, (double)(pc.start - g * (uint64_t)SYNC_TILE)) + pc.bloc);
+    int state = 0;
+    float peak_val = -INFINITY;
+    uint64_t peak_ind = 0;
+    c32 peak_P = mk(0.f, 0.f);
+    bool open_at_stream_end = false;
+    for (;;) {
+      const uint64_t len = pc.end - pc.start + 1;
+      for (uint64_t k = 0; k < len; k++) {
+        const float u = p.cand_u[pc.val_off + k];
+        const uint64_t i = pc.start + k;
+        for (;;) {
+          if (state == 0) {
+            if (u > avg * p.rise) {
+              state = 1;
+              continue;
+            }
+            avg = p.alpha * u + one_m_alpha * avg;
+            break;
           }
-          avg = p.alpha * u + one_m_alpha * avg;
-          break;
+          if (u > peak_val) {
+            peak_val = u;
+            peak_ind = i;
+            peak_P = p.cand_P[pc.val_off + k];
+            avg = p.alpha * u + one_m_alpha * avg;
+            break;
+          }
+          if (u > avg * p.fall) {
+            avg = p.alpha * u + one_m_alpha * avg;
+            break;
+          }
+          if (WRITE) {
+            p.peaks[wbase + nflag] = peak_ind;
+            p.peak_P[wbase + nflag] = peak_P;
+          }
+          nflag++;
+          state = 0;
+          peak_val = -INFINITY;
         }
-        if (u > peak_val) {
-          peak_val = u;
-          peak_ind = i;
-          peak_P = p.cand_P[pc.val_off + k];
-          avg = p.alpha * u + one_m_alpha * avg;
-          break;
-        }
-        if (u > avg * p.fall) {
-          avg = p.alpha * u + one_m_alpha * avg;
-          break;
-        }
-        if (WRITE) {
-          p.peaks[wbase + nflag] = peak_ind;
-          p.peak_P[wbase + nflag] = peak_P;
-        }
-        nflag++;
-        state = 0;
-        peak_val = -INFINITY;
       }
-    }
-    // does the interval continue in the next tile?
-    const uint64_t gn = g + 1;
-    if (pc.end + 1 == gn * (uint64_t)SYNC_TILE && gn < p.ntiles && p.tile_npieces[gn] > 0) {
-      const SyncPiece nx = p.tile_pieces[gn * SYNC_MAXP];
-      if (nx.start == pc.end + 1) {
-        pc = nx;
-        g = gn;
-        continue;
+      // does the interval continue in the next tile?
+      const uint64_t gn = g + 1;
+      if (pc.end + 1 == gn * (uint64_t)SYNC_TILE && gn < p.ntiles && p.tile_npieces[gn] > 0) {
+        const SyncPiece nx = p.pieces[p.tile_first[gn]];
+        if (nx.start == pc.end + 1) {
+          pc = nx;
+          g = gn;
+          continue;
+        }
       }
+      if (pc.end + 1 >= p.nsamples) open_at_stream_end = true;
+      break;
     }
-    if (pc.end + 1 >= p.nsamples) open_at_stream_end = true;
-    break;
-  }
-  // the sample after the interval has u <= theta: it closes an open run (unless the stream ended)
-  if (state == 1 && !open_at_stream_end) {
-    if (WRITE) {
-      p.peaks[wbase + nflag] = peak_ind;
-      p.peak_P[wbase + nflag] = peak_P;
+    // the sample after the interval has u <= theta: it closes an open run (unless the stream ended)
+    if (state == 1 && !open_at_stream_end) {
+      if (WRITE) {
+        p.peaks[wbase + nflag] = peak_ind;
+        p.peak_P[wbase + nflag] = peak_P;
+      }
+      nflag++;
     }
-    nflag++;
   }
-  if (!WRITE) p.counts[id] = nflag;
+  if (!WRITE) p.counts[g0] = nflag;
 }
 
 // ---------------------------------------------------------------------------------

@@ -760,7 +760,11 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   vec_init(&r->pay_len, sizeof(uint32_t));
   vec_init(&r->pay_ok, 1);
   r->st.samples = n;
-  if (n == 0) return r;
+  if (n == 0) {
+    *(uint64_t *)vec_push(&r->raw_off, 1) = 0;
+    *(uint64_t *)vec_push(&r->pay_off, 1) = 0;
+    return r;
+  }
 
   /* --- chan_filt ------------------------------------------------------- */
   ofdm_c32 *y = (ofdm_c32 *)vec_push(&r->y, n);

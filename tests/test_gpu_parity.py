@@ -1,0 +1,105 @@
+"""Parity proper: the HIP engine (through the C ABI) against the CPU oracle on the same
+seeded inputs, stage by stage at the reference's --log probe points.
+
+Bars (BASELINE.json north_star): bit-exact packets and CRC verdicts; float symbols within
+1e-5 (relative to the signal scale where the magnitudes exceed 1).  Two stages are held to
+a stronger bar by construction: the channel filter (one fmaf chain per output) and the
+Schmidl-Cox metric (Q23.40 moving sums) are bit-identical, which is what makes the timing
+flags identical."""
+import numpy as np
+import pytest
+
+from helpers import loopback_stream, make_cfg, make_payloads
+from ofdm_uhd_amd import _abi, config
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # mod, N, occ, CP, payload, packets, snr, cfo(bins)
+    ("qpsk", 512, 200, 128, 1026, 6, 30.0, 0.0),      # BASELINE config 2 shape
+    ("bpsk", 512, 200, 128, 300, 5, 30.0, 0.05),      # BASELINE config 1 shape
+    ("qpsk", 512, 200, 128, 1026, 6, 30.0, 0.3),      # CFO: first packet lost, chained frames
+    ("8psk", 256, 120, 64, 500, 4, 30.0, 0.0),        # nbits = 3: chunks straddle bytes
+    ("qam16", 2048, 1200, 512, 4091, 3, 30.0, 0.0),   # BASELINE config 3, largest legal packet
+    ("qam64", 1024, 600, 256, 2000, 3, 36.0, 0.1),
+    ("qam64", 4096, 2400, 1024, 4091, 3, 36.0, 0.0),  # BASELINE config 5 sizing
+    ("qam256", 64, 48, 16, 100, 4, 40.0, 0.0),        # smallest FFT, 8 threads per symbol
+    ("bpsk", 128, 64, 32, 64, 4, 30.0, 0.0),
+    ("qpsk", 512, 200, 128, 1026, 4, 30.0, 1.3),      # coarse offset +1 bin
+    ("qpsk", 512, 200, 128, 1026, 4, 30.0, -2.4),     # coarse offset -2 bins
+]
+RX_TAPS = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK,
+           _abi.TAP_RX_PACKETS)
+
+
+def _engine(cfg):
+    from ofdm_uhd_amd import engine
+    return engine.Engine(cfg=cfg)
+
+
+@pytest.mark.parametrize("mod,N,occ,CP,plen,npkt,snr,cfo", CASES)
+def test_tx_parity(orc, mod, N, occ, CP, plen, npkt, snr, cfo):
+    cfg = make_cfg(mod, N, occ, CP)
+    eng = _engine(cfg)
+    pay = make_payloads(npkt, plen)
+    assert eng.make_packets(pay) == [orc.make_packet(cfg, p) for p in pay]      # bytes: bit-exact
+    eng.set_taps(_abi.TAP_TX_FREQ)
+    iq_g = eng.tx(pay)
+    iq_o, freq_o, _ = orc.tx(cfg, pay, want_taps=True)
+    assert np.array_equal(eng.tap(_abi.TAP_TX_FREQ), freq_o)                    # constellation look-ups: exact
+    assert len(iq_g) == len(iq_o)
+    assert np.abs(iq_g - iq_o).max() < 1e-5                                      # |IQ| error bound of the north star
+    assert eng.last_stats["symbols"] * (N + CP) == len(iq_g)
+    eng.close()
+
+
+@pytest.mark.parametrize("mod,N,occ,CP,plen,npkt,snr,cfo", CASES)
+def test_rx_parity(orc, mod, N, occ, CP, plen, npkt, snr, cfo):
+    cfg = make_cfg(mod, N, occ, CP)
+    eng = _engine(cfg)
+    pay = make_payloads(npkt, plen)
+    x = loopback_stream(orc, cfg, pay, snr_db=snr, cfo_bins=cfo)                # ONE input for both receivers
+    mask = 0
+    for t in RX_TAPS:
+        mask |= 1 << t
+    ro = orc.rx(cfg, x, mask)
+    eng.set_taps(*RX_TAPS)
+    pk = eng.rx(x)
+    # integer / decision outputs: bit-exact
+    assert pk == ro.packets
+    assert eng.tap(_abi.TAP_RX_PACKETS).tobytes() == ro.tap(_abi.TAP_RX_PACKETS).tobytes()
+    assert eng.tap(_abi.TAP_RX_PEAKS).tolist() == ro.tap(_abi.TAP_RX_PEAKS).tolist()
+    assert eng.tap(_abi.TAP_RX_FRAMES).tolist() == ro.tap(_abi.TAP_RX_FRAMES).tolist()
+    for k in ("symbols", "samples", "peaks", "frames", "headers_ok", "packets", "crc_ok", "chained_frames"):
+        assert eng.last_stats[k] == ro.stats[k], k
+    assert eng.last_stats["overflow"] == 0
+    # bit-identical by construction
+    assert np.array_equal(eng.tap(_abi.TAP_RX_CHAN_FILT), ro.tap(_abi.TAP_RX_CHAN_FILT))
+    assert np.array_equal(eng.tap(_abi.TAP_RX_METRIC), ro.tap(_abi.TAP_RX_METRIC))
+    # float stages: 1e-5 in units of the stage's signal scale
+    assert np.abs(eng.tap(_abi.TAP_RX_ANGLES) - ro.tap(_abi.TAP_RX_ANGLES)).max() < 1e-5
+    for tap in (_abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK):
+        a, b = ro.tap(tap), eng.tap(tap)
+        assert a.shape == b.shape
+        if a.size:
+            assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(a))), tap
+    # every packet whose preamble was derotated with a settled frequency estimate is recovered
+    good = [p for ok, p in pk if ok]
+    assert all(p in pay for p in good)
+    if abs(cfo) < 0.1:
+        assert good == pay
+    eng.close()
+
+
+def test_channel_parity(orc):
+    cfg = make_cfg("qpsk")
+    eng = _engine(cfg)
+    x = orc.tx(cfg, make_payloads(2, 500), lead=100, tail=100)
+    a = eng.channel(x, sigma=0.01, cfo=0.002, seed=123, stream_id=7, index0=5)
+    b = x.copy()
+    orc.channel(b, sigma=0.01, cfo=0.002, seed=123, stream_id=7, index0=5)
+    # same Philox counters, libm vs ocml transcendental: a few ulp
+    assert np.abs(a - b).max() < 1e-6
+    n = a[:100] - x[:100] * np.exp(1j * 0.002 * (5 + np.arange(100)))
+    assert 0.005 < np.std(n.real) < 0.0095 and abs(np.mean(n)) < 0.004
+    eng.close()

@@ -1,0 +1,124 @@
+"""Pins the C oracle (oracle/ofdm_oracle.c) against the independent float64 NumPy
+model (tests/np_model.py), stage by stage, and checks the round trip.  The reference
+has no golden vectors for this path (parity unpinned at the GNU Radio
+boundary); what can be pinned from it is covered in test_constants / test_packet_utils.
+"""
+import numpy as np
+import pytest
+
+import np_model as npm
+from helpers import loopback_stream, make_cfg, make_payloads
+from ofdm_uhd_amd import _abi, config
+
+CASES = [
+    ("qpsk", 512, 200, 128, 1026, 4, 0.0),
+    ("bpsk", 512, 200, 128, 300, 4, 0.05),
+    ("qpsk", 512, 200, 128, 1026, 5, 0.3),     # first packet lost, a bogus header chains frames
+    ("8psk", 256, 120, 64, 500, 3, 0.0),
+    ("qam16", 2048, 1200, 512, 4091, 2, 0.0),
+    ("qam64", 1024, 600, 256, 2000, 3, 0.1),
+    ("qam256", 512, 200, 128, 777, 3, 0.0),
+]
+ALL_TAPS = sum(1 << t for t in (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ,
+                                _abi.TAP_RX_SINK, _abi.TAP_RX_PACKETS))
+
+
+@pytest.mark.parametrize("mod,N,occ,CP,plen,npkt,cfo", CASES)
+def test_tx_matches_numpy_model(orc, mod, N, occ, CP, plen, npkt, cfo):
+    cfg = make_cfg(mod, N, occ, CP)
+    pay = make_payloads(npkt, plen)
+    iq, freq, framed = orc.tx(cfg, pay, want_taps=True)
+    f2 = npm.tx_freq(cfg, pay)
+    assert freq.shape == f2.shape
+    assert np.abs(freq - f2).max() < 1e-7          # table look-ups: float32 rounding of the constellation only
+    t2 = npm.tx_time(cfg, f2)
+    assert len(iq) == len(t2)
+    assert np.abs(iq - t2).max() < 5e-7            # float32 FFT vs float64
+    # symbol count: preamble + ceil(8*len / (carriers*nbits)) per packet
+    ncar = len(config.carrier_map(occ, N))
+    nb = npm.nbits_of(cfg)
+    per = sum(1 + -(-8 * len(p) // (ncar * nb)) for p in framed)
+    assert len(iq) == per * (N + CP)
+
+
+@pytest.mark.parametrize("mod,N,occ,CP,plen,npkt,cfo", CASES)
+def test_rx_matches_numpy_model(orc, mod, N, occ, CP, plen, npkt, cfo):
+    cfg = make_cfg(mod, N, occ, CP)
+    pay = make_payloads(npkt, plen)
+    iq = loopback_stream(orc, cfg, pay, snr_db=30.0, cfo_bins=cfo)
+    r = orc.rx(cfg, iq, ALL_TAPS)
+    m = npm.rx(cfg, iq)
+    assert np.abs(r.tap(_abi.TAP_RX_CHAN_FILT) - m["y"]).max() < 2e-6
+    assert np.abs(r.tap(_abi.TAP_RX_METRIC) - m["u"]).max() < 2e-5
+    assert list(r.tap(_abi.TAP_RX_PEAKS)) == list(m["peaks"])
+    assert np.abs(r.tap(_abi.TAP_RX_ANGLES) - m["angles"]).max() < 1e-5
+    # closed-form sampler (np_model.sampler_frames) == the automaton the oracle runs
+    assert [tuple(x) for x in r.tap(_abi.TAP_RX_FRAMES)] == [tuple(x) for x in m["frames"]]
+    F = r.tap(_abi.TAP_RX_FFT)
+    F2 = np.array([s for _, s in m["fft"]])
+    assert F.shape == F2.shape and np.abs(F - F2).max() < 1e-4 * max(1.0, np.abs(F2).max())
+    # junk frames (false trigger at the burst end) have ill-conditioned equalisers: compare in relative terms
+    A = r.tap(_abi.TAP_RX_ACQ)
+    A2 = np.array([s for _, s in m["acq"]])
+    assert A.shape == A2.shape
+    assert np.all(np.abs(A - A2) <= 2e-4 * (1.0 + np.abs(A2)))
+    S = r.tap(_abi.TAP_RX_SINK)
+    S2 = np.array(m["sink"])
+    nmap = len(config.carrier_map(occ, occ))
+    assert S.shape[0] == S2.shape[0]
+    assert np.all(np.abs(S[:, :nmap] - S2) <= 2e-4 * (1.0 + np.abs(S2)))
+    assert r.packets == m["packets"]
+    assert r.stats["packets"] == len(r.packets) and r.stats["crc_ok"] == sum(ok for ok, _ in r.packets)
+
+
+def test_loopback_recovers_every_packet(orc):
+    # 64-QAM needs more than the reference's default 30 dB: the one-tap equaliser is estimated from a
+    # single half-loaded preamble symbol, which costs ~3 dB
+    for mod, plen, snr in (("bpsk", 64, 30.0), ("qpsk", 1026, 30.0), ("qam16", 1500, 30.0), ("qam64", 2000, 36.0)):
+        cfg = make_cfg(mod)
+        pay = make_payloads(6, plen, seed=7, variant="ref")
+        iq = loopback_stream(orc, cfg, pay, snr_db=snr)
+        r = orc.rx(cfg, iq)
+        assert [p for ok, p in r.packets if ok] == pay
+        # GR's metric spikes when the burst ends: one extra flag, no extra packet
+        assert r.stats["peaks"] == len(pay) + 1 and r.stats["packets"] == len(pay)
+
+
+def test_ragged_and_empty_payloads(orc):
+    cfg = make_cfg("qpsk")
+    pay = make_payloads(7, [0, 1, 4, 5, 100, 1026, 4091], seed=11)
+    iq = loopback_stream(orc, cfg, pay)
+    r = orc.rx(cfg, iq)
+    assert [p for ok, p in r.packets] == pay
+    # a 0..3 byte payload still passes the CRC (message is >= 4 bytes)
+    assert all(ok for ok, _ in r.packets)
+    # no packets, no samples
+    assert orc.rx(cfg, np.zeros(0, np.complex64)).packets == []
+    noise = np.zeros(20000, np.complex64)
+    orc.channel(noise, sigma=0.01)
+    assert orc.rx(cfg, noise).packets == []
+
+
+def test_sampler_timeout_path(orc):
+    """A packet, more than 1001 symbol times of noise (sampler time-out -> NO_SIG grid), another
+    packet: the closed form used on the GPU must agree with the automaton."""
+    cfg = make_cfg("qpsk", 64, 48, 16)
+    N, CP = 64, 16
+    pay = make_payloads(2, 60, seed=5)
+    a = orc.tx(cfg, pay[:1], lead=2 * N, tail=0)
+    gap = np.zeros(1100 * (N + CP) + 37, np.complex64)
+    b = orc.tx(cfg, pay[1:], lead=0, tail=(N + CP) + 2 * N)
+    iq = np.concatenate([a, gap, b])
+    orc.channel(iq, sigma=float(np.sqrt(np.mean(np.abs(a[2 * N:]) ** 2) / 1000.0)))
+    r = orc.rx(cfg, iq, 1 << _abi.TAP_RX_METRIC)
+    peaks = r.tap(_abi.TAP_RX_PEAKS)
+    frames = npm.sampler_frames(peaks, len(iq), N, CP, cfg.sampler_timeout)
+    assert [tuple(x) for x in r.tap(_abi.TAP_RX_FRAMES)] == frames
+    assert max(k for _, k in frames) == cfg.sampler_timeout + 1   # the time-out really fired
+    assert [p for ok, p in r.packets if ok] == pay
+
+
+def test_pad_symbols_are_counter_based(orc):
+    # the mapper's rand()%arity fill is replaced by a hash of (seed, packet, slot): deterministic
+    for args in ((1, 2, 3, 4), (0x0FD30000, 0, 4140, 64), (2 ** 63, 65535, 10 ** 6, 256)):
+        assert orc.lib().orc_pad_symbol(*args) == npm.pad_symbol(*args)
