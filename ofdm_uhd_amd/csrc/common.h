@@ -102,6 +102,41 @@ __device__ __forceinline__ long long q40_clamped(float v) {
 }
 __device__ __forceinline__ double q40_to_double(long long s) { return (double)s * Q40_INV; }
 
+// ---- complex_to_arg for the sample-and-held fine-frequency estimate ------------------------
+// Plain float32 operations (Cephes-style atanf, ~2 ulp), NOT ocml's atan2f: the CPU restatement
+// evaluates the same operations and gets the same bits.  The NCO integrates this angle over
+// thousands of samples; a 1-ulp difference between two libm's would grow to 1e-4 rad.
+__device__ __forceinline__ float det_atanf_pos(float x) {
+  float y0;
+  if (x > 2.414213562373095f) {
+    y0 = 1.5707963267948966f;
+    x = -(1.0f / x);
+  } else if (x > 0.4142135623730950f) {
+    y0 = 0.7853981633974483f;
+    x = (x - 1.0f) / (x + 1.0f);
+  } else {
+    y0 = 0.0f;
+  }
+  float z = x * x;
+  float p = 8.05374449538e-2f;
+  p = p * z - 1.38776856032e-1f;
+  p = p * z + 1.99777106478e-1f;
+  p = p * z - 3.33329491539e-1f;
+  p = p * z;
+  p = p * x + x;
+  return y0 + p;
+}
+__device__ __forceinline__ float det_atan2f(float y, float x) {
+  if (x == 0.0f) {
+    if (y > 0.0f) return 1.5707963267948966f;
+    if (y < 0.0f) return -1.5707963267948966f;
+    return 0.0f;
+  }
+  const float a = det_atanf_pos(fabsf(y / x));
+  const float r = (x > 0.0f) ? a : (3.14159265358979323846f - a);
+  return (y < 0.0f) ? -r : r;
+}
+
 // ---- misc -----------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t pad_symbol_hash(uint64_t seed, uint64_t pkt, uint64_t slot,
                                                              uint32_t arity) {

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_frames(FramesParams q) {
   if (j >= q.npeaks) return;
   const uint64_t p = q.peaks[j];
   const c32 P = q.peak_P[j];
-  const float ang = atan2f(P.im, P.re);
+  const float ang = det_atan2f(P.im, P.re);  // complex_to_arg, bit-reproducible form
   q.angle[j] = ang;
   const double st = (double)(q.sens * ang);
   q.step[j] = st;

@@ -72,6 +72,41 @@ static inline ofdm_c32 cdiv(ofdm_c32 a, ofdm_c32 b) {
 }
 static inline float cnorm(ofdm_c32 a) { return a.re * a.re + a.im * a.im; }
 
+/* complex_to_arg for the sample-and-held fine-frequency estimate.  Written out in plain float32
+ * operations (Cephes-style atanf: two range reductions + a degree-9 odd polynomial, ~2 ulp) so
+ * that the GPU evaluates the very same operations and gets the same bits: the NCO integrates this
+ * angle over thousands of samples, which would turn a 1-ulp libm/ocml difference into 1e-4 rad. */
+static inline float det_atanf_pos(float x) {
+  float y0;
+  if (x > 2.414213562373095f) {
+    y0 = 1.5707963267948966f;
+    x = -(1.0f / x);
+  } else if (x > 0.4142135623730950f) {
+    y0 = 0.7853981633974483f;
+    x = (x - 1.0f) / (x + 1.0f);
+  } else {
+    y0 = 0.0f;
+  }
+  float z = x * x;
+  float p = 8.05374449538e-2f;
+  p = p * z - 1.38776856032e-1f;
+  p = p * z + 1.99777106478e-1f;
+  p = p * z - 3.33329491539e-1f;
+  p = p * z;
+  p = p * x + x;
+  return y0 + p;
+}
+float orc_atan2f(float y, float x) {
+  if (x == 0.0f) {
+    if (y > 0.0f) return 1.5707963267948966f;
+    if (y < 0.0f) return -1.5707963267948966f;
+    return 0.0f;
+  }
+  float a = det_atanf_pos(fabsf(y / x));
+  float r = (x > 0.0f) ? a : (3.14159265358979323846f - a);
+  return (y < 0.0f) ? -r : r;
+}
+
 static int ilog2_ceil(unsigned v) {
   int n = 0;
   while ((1u << n) < v) n++;
@@ -789,7 +824,7 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   double *step = (double *)malloc(sizeof(double) * (npk + 1));
   Phi[0] = 0.0;
   for (uint64_t j = 0; j < npk; j++) {
-    ang[j] = atan2f(P[pk[j]].im, P[pk[j]].re);
+    ang[j] = orc_atan2f(P[pk[j]].im, P[pk[j]].re);
     step[j] = (double)(sens * ang[j]);
     if (j + 1 < npk) Phi[j + 1] = Phi[j] + step[j] * (double)(pk[j + 1] - pk[j]);
   }

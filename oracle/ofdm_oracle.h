@@ -15,6 +15,7 @@ extern "C" {
 typedef struct orc_rx_result orc_rx_result;
 
 int orc_nbits(const ofdm_cfg *cfg);
+float orc_atan2f(float y, float x);
 uint32_t orc_crc32(const uint8_t *buf, uint64_t len);
 int orc_framed_len(const ofdm_cfg *cfg, uint32_t payload_len, uint32_t *out);
 int orc_make_packet(const ofdm_cfg *cfg, const uint8_t *payload, uint32_t len, uint8_t *out, uint32_t *outlen);

@@ -30,6 +30,8 @@ def lib():
         vp = C.c_void_p
         L.orc_crc32.restype = C.c_uint32
         L.orc_crc32.argtypes = [vp, C.c_uint64]
+        L.orc_atan2f.restype = C.c_float
+        L.orc_atan2f.argtypes = [C.c_float, C.c_float]
         L.orc_framed_len.argtypes = [C.POINTER(_abi.ofdm_cfg), C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_make_packet.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
         L.orc_unmake_packet.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, C.c_uint32, vp, C.POINTER(C.c_uint32),
