@@ -129,11 +129,30 @@ def _declare(lib):
     return lib
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the name libofdm_hip.so needs).  If that copy is mapped first the dynamic linker
+    hands it to us as well; if /opt/rocm's copy came first, a later ``import torch`` would map a SECOND
+    runtime and find "No HIP GPUs".  So when torch is installed, map its runtime before ours --
+    without importing torch."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load libofdm_hip.so (once).  Raises ImportError if it is missing: the HIP
     engine IS the implementation, nothing falls back to the CPU."""
     global _LIB
     if _LIB is None:
+        _preload_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "libofdm_hip.so not found at %s -- build it first (__graft_entry__.build() or "

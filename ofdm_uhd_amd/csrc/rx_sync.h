@@ -16,12 +16,22 @@
 // record a new peak on samples with u > theta; any sample with u <= theta closes an open
 // run.  Hence maximal intervals {u > theta} are independent sub-problems once avg at their
 // first sample is known, and avg is a linear recurrence (tile summaries + look-back).
+//
+// Two-speed metric.  The timing flag is an arg-max of u, so u must carry the oracle's exact
+// bits wherever the detector can look -- but that is ~1 % of the stream.  Every tile first
+// gets a cheap float32 evaluation of the metric (moving sums re-anchored per tile, so the
+// rounding error stays ~1e-6 and does not drift); samples with u_approx > theta - GUARD mark
+// a neighbourhood that is then re-evaluated in the normative Q23.40 fixed point (bit-exact,
+// evaluation-order independent).  The float32 values also feed the detector's running
+// average, whose rounding in the reference is of the same order.
 #pragma once
 #include "common.h"
 
 #define SYNC_THREADS 256
 #define SYNC_V 8                            // consecutive samples per thread
 #define SYNC_TILE (SYNC_THREADS * SYNC_V)   // 2048 samples per tile
+#define SYNC_GUARD 1.0e-3f                  // guard band of the float32 pre-selection
+#define SYNC_MAX_TAPS OFDM_MAX_TAPS
 
 struct SyncPiece {
   uint64_t start;    // absolute sample index of the first candidate of the piece
@@ -33,10 +43,11 @@ struct SyncPiece {
 struct SyncParams {
   int N, D, CP;
   int HX;         // x history kept in LDS (padded tap count, multiple of 8)
-  int HY;         // y history (2*D)
+  int HY;         // y history (2*D + CP, multiple of 8)
   int HM;         // M history (CP)
   int ntaps_pad;  // multiple of 8
   int tiles_per_seg, nwarm;
+  int exact_all;  // metric tap: evaluate every sample in fixed point
   uint64_t nsamples, ntiles;
   float tapcp;       // float(1/CP)
   float cand_thr;    // -max(rise, fall)
@@ -44,7 +55,6 @@ struct SyncParams {
   double decay;      // double(1.0f - alpha)
   const c32* x;
   c32* y;
-  const float* taps;
   float* metric_tap;  // optional [nsamples]
   // outputs
   double* tile_B;          // [ntiles] zero-init running average over the tile
@@ -58,16 +68,31 @@ struct SyncParams {
   uint64_t cand_cap;
   unsigned long long* cand_count;  // device counter
   unsigned int* overflow;          // device flag
+  float taps[SYNC_MAX_TAPS + 56];   // in the kernel-argument segment: read with scalar loads
 };
 
 __host__ __device__ inline int sync_lp(int i) { return i + (i >> 3); }
 
-__host__ inline size_t sync_lds_bytes(const SyncParams& p) {
-  size_t xs = (size_t)(sync_lp(p.HX + SYNC_TILE) + 2) * sizeof(c32);
-  size_t ys = (size_t)(sync_lp(p.HY + SYNC_TILE) + 2) * sizeof(c32);
-  size_t ms = (size_t)(sync_lp(p.HM + SYNC_TILE) + 2) * sizeof(float);
-  size_t misc = 1024;
-  return xs + ys + ((ms + 15) & ~(size_t)15) + misc;
+struct SyncLds {
+  size_t xs, ys, ms, me, ue, misc, total;
+};
+__host__ __device__ inline SyncLds sync_lds_layout(int HX, int HY, int HM, int CP) {
+  SyncLds l;
+  size_t o = 0;
+  l.xs = o;
+  o += (size_t)(sync_lp(HX + SYNC_TILE) + 2) * sizeof(c32);
+  l.ys = o;
+  o += (size_t)(sync_lp(HY + SYNC_TILE) + 2) * sizeof(c32);
+  l.ms = o;
+  o += ((size_t)(sync_lp(HM + SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  l.me = o;  // exact M over [amin-CP+1, bmax]
+  o += ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
+  l.ue = o;  // exact u over [amin, bmax]
+  o += (size_t)(SYNC_TILE + 8) * sizeof(float);
+  l.misc = o;
+  o += 1024;
+  l.total = o;
+  return l;
 }
 
 // affine map a -> A*a + b, composition "first f then g"
@@ -81,19 +106,185 @@ __device__ __forceinline__ Aff aff_then(Aff f, Aff g) {
   return r;
 }
 
-__global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
+// ---- DPP wave scan (float): 4 row_shr steps inside rows of 16, then two row broadcasts ------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_incl_scan_f32(float v) {
+  v += dpp_f<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_f<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_f<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_f<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_f<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v += dpp_f<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+struct F3 {
+  float a, b, c;
+};
+
+// Block-wide (4 waves) exclusive scan of three floats + block sum of three more, one barrier pair.
+// scratch: 4 waves x 6 floats.
+__device__ __forceinline__ void block_scan3_sum3(F3 v, F3 s, float* scratch, F3* excl, F3* total, F3* sum) {
+  const int lane = lane_id(), w = wave_id();
+  F3 inc;
+  inc.a = wave_incl_scan_f32(v.a);
+  inc.b = wave_incl_scan_f32(v.b);
+  inc.c = wave_incl_scan_f32(v.c);
+  F3 rs;
+  rs.a = wave_incl_scan_f32(s.a);
+  rs.b = wave_incl_scan_f32(s.b);
+  rs.c = wave_incl_scan_f32(s.c);
+  if (lane == WAVE - 1) {
+    scratch[w * 6 + 0] = inc.a;
+    scratch[w * 6 + 1] = inc.b;
+    scratch[w * 6 + 2] = inc.c;
+    scratch[w * 6 + 3] = rs.a;
+    scratch[w * 6 + 4] = rs.b;
+    scratch[w * 6 + 5] = rs.c;
+  }
+  __syncthreads();
+  F3 base = {0.f, 0.f, 0.f}, tot = {0.f, 0.f, 0.f}, sm = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
+    const float a = scratch[i * 6 + 0], b = scratch[i * 6 + 1], c = scratch[i * 6 + 2];
+    if (i < w) {
+      base.a += a;
+      base.b += b;
+      base.c += c;
+    }
+    tot.a += a;
+    tot.b += b;
+    tot.c += c;
+    sm.a += scratch[i * 6 + 3];
+    sm.b += scratch[i * 6 + 4];
+    sm.c += scratch[i * 6 + 5];
+  }
+  __syncthreads();
+  excl->a = base.a + inc.a - v.a;
+  excl->b = base.b + inc.b - v.b;
+  excl->c = base.c + inc.c - v.c;
+  *total = tot;
+  *sum = sm;
+}
+
+struct Q3 {
+  long long pr, pi, r;
+};
+
+// ---------------------------------------------------------------------------------
+// Normative (Q23.40) evaluation of u = Mbar - 1 for the tile-relative samples [amin, bmax]:
+//   me[k]  exact M of sample amin-CP+1+k        (k < bmax-amin+CP)
+//   ue[k]  exact u of sample amin+k
+//   Pe[k]  exact P of sample amin+k
+// Rare path (only where the float32 pre-selection found something): kept out of line so that it
+// does not weigh on the register allocation of the streaming loop.
+// ---------------------------------------------------------------------------------
+__device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* ue, c32* Pe, long long* sc_i64, int amin,
+                                              int bmax, int D, int CP, int HY, int64_t t0s, int64_t qvalid, int64_t mvalid,
+                                              float tapcp) {
+  const int tid = threadIdx.x;
+#define QTERM(m)                                                                   \
+  ([&]() -> Q3 {                                                                   \
+    Q3 q_ = {0, 0, 0};                                                             \
+    if (t0s + (int64_t)(m) >= qvalid) {                                            \
+      const c32 a_ = ys[sync_lp(HY + (m))];                                        \
+      const c32 d_ = ys[sync_lp(HY + (m) - D)];                                    \
+      const c32 c_ = cmul_conj(a_, d_);                                            \
+      q_.pr = q40_clamped(c_.re);                                                  \
+      q_.pi = q40_clamped(c_.im);                                                  \
+      q_.r = q40_clamped(a_.re * a_.re + a_.im * a_.im);                           \
+    }                                                                              \
+    return q_;                                                                     \
+  }())
+  const int s0 = amin - CP;               // anchor sample (tile-relative, may be negative)
+  const int n_e = bmax - s0;              // samples s0+1 .. bmax get an exact M
+  const int len = bmax - amin + 1;
+  // (i) exact window sums at the anchor
+  Q3 an = {0, 0, 0};
+  for (int m = s0 - D + 1 + tid; m <= s0; m += SYNC_THREADS) {
+    const Q3 q = QTERM(m);
+    an.pr += q.pr;
+    an.pi += q.pi;
+    an.r += q.r;
+  }
+  // (ii) per-thread chunk of the delta sequence, scan, exact M
+  const int lc = (n_e + SYNC_THREADS - 1) / SYNC_THREADS;
+  const int k0 = tid * lc, k1 = (k0 + lc < n_e) ? (k0 + lc) : n_e;
+  Q3 tq = {0, 0, 0};
+  for (int k = k0; k < k1; k++) {
+    const int m = s0 + 1 + k;
+    const Q3 a = QTERM(m), b = QTERM(m - D);
+    tq.pr += a.pr - b.pr;
+    tq.pi += a.pi - b.pi;
+    tq.r += a.r - b.r;
+  }
+  long long tot_, anpr, anpi, anr;
+  (void)block_excl_scan_add<long long>(an.pr, sc_i64, &anpr);
+  (void)block_excl_scan_add<long long>(an.pi, sc_i64 + 5, &anpi);
+  (void)block_excl_scan_add<long long>(an.r, sc_i64 + 10, &anr);
+  long long wpr = anpr + block_excl_scan_add<long long>(tq.pr, sc_i64, &tot_);
+  long long wpi = anpi + block_excl_scan_add<long long>(tq.pi, sc_i64 + 5, &tot_);
+  long long wr = anr + block_excl_scan_add<long long>(tq.r, sc_i64 + 10, &tot_);
+  for (int k = k0; k < k1; k++) {
+    const int m = s0 + 1 + k;
+    const Q3 a = QTERM(m), b = QTERM(m - D);
+    wpr += a.pr - b.pr;
+    wpi += a.pi - b.pi;
+    wr += a.r - b.r;
+    const float pre = (float)q40_to_double(wpr);
+    const float pim = (float)q40_to_double(wpi);
+    const float r = (float)q40_to_double(wr);
+    const float num = pre * pre + pim * pim;
+    const float den = r * r;
+    float mm = (den > 0.0f) ? (num / den) : 0.0f;
+    if (!(mm <= 1024.0f)) mm = 1024.0f;
+    if (t0s + m < mvalid) mm = 0.0f;
+    me[k] = mm;
+    if (m >= amin) Pe[m - amin] = mk(pre, pim);
+  }
+  __syncthreads();
+  // (iii) exact CP-length moving sum of M over [amin, bmax]; me[k] holds sample s0+1+k = amin-CP+1+k
+  long long am = 0;
+  for (int k = tid; k < CP; k += SYNC_THREADS) am += q40_from_float(me[k]);  // samples amin-CP+1 .. amin
+  const int lc2 = (len + SYNC_THREADS - 1) / SYNC_THREADS;
+  const int j0 = tid * lc2, j1 = (j0 + lc2 < len) ? (j0 + lc2) : len;
+  long long tm = 0;
+  for (int jj = j0; jj < j1; jj++)
+    if (jj > 0) tm += q40_from_float(me[CP - 1 + jj]) - q40_from_float(me[jj - 1]);
+  long long amt;
+  (void)block_excl_scan_add<long long>(am, sc_i64, &amt);
+  long long wm = amt + block_excl_scan_add<long long>(tm, sc_i64 + 5, &tot_);
+  for (int jj = j0; jj < j1; jj++) {
+    if (jj > 0) wm += q40_from_float(me[CP - 1 + jj]) - q40_from_float(me[jj - 1]);
+    const float mbar = (float)(q40_to_double(wm) * (double)tapcp);
+    ue[jj] = mbar + (-1.0f);
+  }
+  __syncthreads();
+#undef QTERM
+}
+
+template <int U>
+__global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
-  const int T = SYNC_TILE;
-  c32* xs = reinterpret_cast<c32*>(smem);
-  c32* ys = xs + (sync_lp(p.HX + T) + 2);
-  float* ms = reinterpret_cast<float*>(ys + (sync_lp(p.HY + T) + 2));
-  unsigned char* misc = smem + (((size_t)((unsigned char*)(ms + sync_lp(p.HM + T) + 2) - smem) + 15) & ~(size_t)15);
+  constexpr int T = SYNC_TILE;
+  const SyncLds L = sync_lds_layout(p.HX, p.HY, p.HM, p.CP);
+  c32* xs = reinterpret_cast<c32*>(smem + L.xs);
+  c32* ys = reinterpret_cast<c32*>(smem + L.ys);
+  float* ms = reinterpret_cast<float*>(smem + L.ms);
+  float* me = reinterpret_cast<float*>(smem + L.me);
+  float* ue = reinterpret_cast<float*>(smem + L.ue);
+  unsigned char* misc = smem + L.misc;
   long long* sc_i64 = reinterpret_cast<long long*>(misc);      // 3 * 5 entries
   double* sc_f64 = reinterpret_cast<double*>(misc + 128);      // 2 * 5 entries
   int* sc_i32 = reinterpret_cast<int*>(misc + 256);            // 5 entries
   unsigned char* cm = misc + 320;                               // 256 candidate masks
   unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 576);  // 2 broadcast words
+  float* sc_f32 = reinterpret_cast<float*>(misc + 608);        // 24 floats
+  int* rng = reinterpret_cast<int*>(misc + 720);               // [0] amin, [1] bmax
 
   const uint64_t seg = blockIdx.x;
   const uint64_t tile_own0 = seg * (uint64_t)p.tiles_per_seg;
@@ -102,8 +293,10 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
   const bool warm = seg > 0;
   const uint64_t tile_first = warm ? tile_own0 - (uint64_t)p.nwarm : tile_own0;
   const uint64_t ws = tile_first * (uint64_t)T;
-  const uint64_t qvalid = warm ? ws + (uint64_t)p.D : 0;
-  const uint64_t mvalid = warm ? ws + 2ull * (uint64_t)p.D - 1 : 0;
+  const int64_t qvalid = warm ? (int64_t)(ws + (uint64_t)p.D) : 0;
+  const int64_t mvalid = warm ? (int64_t)(ws + 2ull * (uint64_t)p.D) - 1 : 0;
+  const int D = p.D, CP = p.CP, HY = p.HY, HM = p.HM;
+  const float inv_cp = 1.0f / (float)CP;
 
   // ---- segment prologue: x history from the stream, y / M history zero ---------
   for (int i = tid; i < p.HX; i += SYNC_THREADS) {
@@ -112,15 +305,18 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
     if (n >= 0 && (uint64_t)n < p.nsamples) v = p.x[n];
     xs[sync_lp(i)] = v;
   }
-  for (int i = tid; i < p.HY; i += SYNC_THREADS) ys[sync_lp(i)] = mk(0.f, 0.f);
-  for (int i = tid; i < p.HM; i += SYNC_THREADS) ms[sync_lp(i)] = 0.0f;
-  long long wpr = 0, wpi = 0, wr = 0, wm = 0;  // moving sums at the sample before the tile
+  for (int i = tid; i < HY; i += SYNC_THREADS) ys[sync_lp(i)] = mk(0.f, 0.f);
+  for (int i = tid; i < HM; i += SYNC_THREADS) ms[sync_lp(i)] = 0.0f;
   const bool x_al16 = ((uintptr_t)p.x & 15) == 0;
   const bool y_al16 = ((uintptr_t)p.y & 15) == 0;
+  // weight of this thread's 8 samples in the tile summary of the detector average
+  const float decay_f = (float)p.decay;
+  const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
   __syncthreads();
 
   for (uint64_t tile = tile_first; tile < tile_own1; tile++) {
     const uint64_t t0 = tile * (uint64_t)T;
+    const int64_t t0s = (int64_t)t0;
     const bool owned = tile >= tile_own0;
 
     // ---- 1. load the tile of x into LDS (coalesced, 16 B per lane when aligned) ---
@@ -147,36 +343,53 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
     __syncthreads();
 
     // ---- 2. channel filter: one fmaf chain per output, taps in order ----------------
-    c32 acc[SYNC_V];
-#pragma unroll
-    for (int j = 0; j < SYNC_V; j++) acc[j] = mk(0.f, 0.f);
     {
-      const int base = p.HX + SYNC_V * tid;  // xs index of output 0 of this thread
-      c32 w[15];
+      c32 acc[SYNC_V];
 #pragma unroll
-      for (int d = 0; d < 15; d++) w[d] = xs[sync_lp(base - 7 + d)];
-      for (int kb = 0; kb < p.ntaps_pad; kb += 8) {
+      for (int j = 0; j < SYNC_V; j++) acc[j] = mk(0.f, 0.f);
+      // HX and 8*tid are multiples of 8, so a padded index splits into a group base plus a small
+      // compile-time offset: lp(8g + r) = 9g + r.  gb = padded index of the group below output 0.
+      const int gb = sync_lp(p.HX + SYNC_V * tid - 8);
+      // U blocks of 8 taps per iteration.  Inside the body the sliding window is renamed by the
+      // compiler (static indices, no moves); it is re-read from LDS at the top of every iteration so
+      // that nothing but one index is carried around the loop.  The taps of an iteration sit in SGPRs.
+      int gw = gb;
+      for (int kb = 0; kb < p.ntaps_pad; kb += 8 * U) {
+        c32 w[15];  // w[d] = x[out0 - kb - 7 + d]
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const float hk = p.taps[kb + i];
+        for (int d = 0; d < 7; d++) w[d] = xs[gw + 1 + d];
 #pragma unroll
-          for (int j = 0; j < SYNC_V; j++) {
-            acc[j].re = fmaf(hk, w[j - i + 7].re, acc[j].re);
-            acc[j].im = fmaf(hk, w[j - i + 7].im, acc[j].im);
+        for (int d = 7; d < 15; d++) w[d] = xs[gw + 9 + (d - 7)];
+        int g = gw - 9;  // group holding the next 7 older samples (index g+9 = sample 0 of the group above)
+#pragma unroll
+        for (int b = 0; b < U; b++) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const float hk = p.taps[kb + b * 8 + i];
+#pragma unroll
+            for (int j = 0; j < SYNC_V; j++) {
+              acc[j].re = fmaf(hk, w[j - i + 7].re, acc[j].re);
+              acc[j].im = fmaf(hk, w[j - i + 7].im, acc[j].im);
+            }
+          }
+          if (b + 1 < U) {
+#pragma unroll
+            for (int d = 14; d >= 8; d--) w[d] = w[d - 8];
+#pragma unroll
+            for (int d = 0; d < 7; d++) w[d] = xs[g + 1 + d];
+            w[7] = xs[g + 9];
+            g -= 9;
           }
         }
-        // slide the window down by 8 samples
-#pragma unroll
-        for (int d = 14; d >= 8; d--) w[d] = w[d - 8];
-        if (kb + 8 < p.ntaps_pad) {
-#pragma unroll
-          for (int d = 0; d < 8; d++) w[d] = xs[sync_lp(base - kb - 15 + d)];
-        }
+        gw -= 9 * U;
       }
-    }
+      const int yb0 = sync_lp(HY + SYNC_V * tid);
 #pragma unroll
-    for (int j = 0; j < SYNC_V; j++) ys[sync_lp(p.HY + SYNC_V * tid + j)] = acc[j];
+      for (int j = 0; j < SYNC_V; j++) ys[yb0 + j] = acc[j];
+    }
     __syncthreads();
+    // x history for the next tile: [T, T+HX) -> [0, HX) (disjoint, T >= HX); the rest of xs is scratch from here on
+    for (int i = tid; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
 
     // ---- 3. y to HBM (owned tiles only), coalesced from LDS ----------------------------
     if (owned) {
@@ -185,7 +398,7 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
 #pragma unroll
         for (int r = 0; r < SYNC_V / 2; r++) {
           const int pi = tid + r * SYNC_THREADS;
-          const int li = sync_lp(p.HY + 2 * pi);
+          const int li = sync_lp(HY + 2 * pi);
           const c32 a = ys[li], b = ys[li + 1];
           dst[pi] = make_float4(a.re, a.im, b.re, b.im);
         }
@@ -194,155 +407,191 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
         for (int r = 0; r < SYNC_V; r++) {
           const int i = tid + r * SYNC_THREADS;
           const uint64_t n = t0 + (uint64_t)i;
-          if (n < p.nsamples) p.y[n] = ys[sync_lp(p.HY + i)];
+          if (n < p.nsamples) p.y[n] = ys[sync_lp(HY + i)];
         }
       }
     }
 
-    // ---- 4. Schmidl-Cox moving sums in Q23.40 --------------------------------------------
-    long long dpr[SYNC_V], dpi[SYNC_V], dr[SYNC_V];
-    long long tpr = 0, tpi = 0, tr = 0;
+    // ---- 4. float32 Schmidl-Cox sums, anchored at the tile start --------------------------
+    float pfr[SYNC_V], pfi[SYNC_V], pfe[SYNC_V];
+    F3 tsum = {0.f, 0.f, 0.f};
+    const int yb = sync_lp(HY + SYNC_V * tid), yb1 = sync_lp(HY - D + SYNC_V * tid), yb2 = sync_lp(HY - 2 * D + SYNC_V * tid);
+    const int mb = sync_lp(HM + SYNC_V * tid);
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
       const int i = SYNC_V * tid + j;
-      const uint64_t n = t0 + (uint64_t)i;
-      const c32 a = ys[sync_lp(p.HY + i)];
-      const c32 d1 = ys[sync_lp(p.HY + i - p.D)];
-      const c32 d2 = ys[sync_lp(p.HY + i - 2 * p.D)];
-      long long npr = 0, npi = 0, nr = 0, opr = 0, opi = 0, orr = 0;
+      const int64_t n = t0s + i;
+      const c32 a = ys[yb + j];
+      const c32 d1 = ys[yb1 + j];
+      const c32 d2 = ys[yb2 + j];
+      float nr = 0.f, ni = 0.f, ne = 0.f, orr = 0.f, oi = 0.f, oe = 0.f;
       if (n >= qvalid) {
-        const c32 c = cmul_conj(a, d1);
-        npr = q40_clamped(c.re);
-        npi = q40_clamped(c.im);
-        nr = q40_clamped(a.re * a.re + a.im * a.im);
+        nr = fmaf(a.re, d1.re, a.im * d1.im);
+        ni = fmaf(a.im, d1.re, -(a.re * d1.im));
+        ne = fmaf(a.re, a.re, a.im * a.im);
       }
-      if (n >= qvalid + (uint64_t)p.D) {
-        const c32 c = cmul_conj(d1, d2);
-        opr = q40_clamped(c.re);
-        opi = q40_clamped(c.im);
-        orr = q40_clamped(d1.re * d1.re + d1.im * d1.im);
+      if (n >= qvalid + D) {
+        orr = fmaf(d1.re, d2.re, d1.im * d2.im);
+        oi = fmaf(d1.im, d2.re, -(d1.re * d2.im));
+        oe = fmaf(d1.re, d1.re, d1.im * d1.im);
       }
-      tpr += npr - opr;
-      tpi += npi - opi;
-      tr += nr - orr;
-      dpr[j] = tpr;
-      dpi[j] = tpi;
-      dr[j] = tr;
+      tsum.a += nr - orr;
+      tsum.b += ni - oi;
+      tsum.c += ne - oe;
+      pfr[j] = tsum.a;
+      pfi[j] = tsum.b;
+      pfe[j] = tsum.c;
     }
-    long long totpr, totpi, totr;
-    const long long epr = block_excl_scan_add<long long>(tpr, sc_i64, &totpr);
-    const long long epi = block_excl_scan_add<long long>(tpi, sc_i64 + 5, &totpi);
-    const long long er = block_excl_scan_add<long long>(tr, sc_i64 + 10, &totr);
-    c32 Pv[SYNC_V];
+    // anchor: the window sums at the sample before the tile, summed afresh from the history
+    F3 anc = {0.f, 0.f, 0.f};
+    for (int m = -D + tid; m < 0; m += SYNC_THREADS) {
+      if (t0s + m >= qvalid) {
+        const c32 a = ys[sync_lp(HY + m)];
+        const c32 d1 = ys[sync_lp(HY + m - D)];
+        anc.a += fmaf(a.re, d1.re, a.im * d1.im);
+        anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
+        anc.c += fmaf(a.re, a.re, a.im * a.im);
+      }
+    }
+    F3 ex3, tot3, anch;
+    block_scan3_sum3(tsum, anc, sc_f32, &ex3, &tot3, &anch);
     float Mv[SYNC_V];
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
-      const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
-      const float pre = (float)q40_to_double(wpr + epr + dpr[j]);
-      const float pim = (float)q40_to_double(wpi + epi + dpi[j]);
-      const float r = (float)q40_to_double(wr + er + dr[j]);
-      const float num = pre * pre + pim * pim;
+      const int64_t n = t0s + SYNC_V * tid + j;
+      const float pre = anch.a + ex3.a + pfr[j];
+      const float pim = anch.b + ex3.b + pfi[j];
+      const float r = anch.c + ex3.c + pfe[j];
+      const float num = fmaf(pre, pre, pim * pim);
       const float den = r * r;
-      float m = (den > 0.0f) ? (num / den) : 0.0f;
+      float m = (den > 0.0f) ? __fdividef(num, den) : 0.0f;
       if (!(m <= 1024.0f)) m = 1024.0f;
       if (n < mvalid) m = 0.0f;
-      Pv[j] = mk(pre, pim);
       Mv[j] = m;
-      ms[sync_lp(p.HM + SYNC_V * tid + j)] = m;
+      ms[mb + j] = m;
     }
-    wpr += totpr;
-    wpi += totpi;
-    wr += totr;
     __syncthreads();
 
-    // ---- 5. CP-length moving average of M, minus one -----------------------------------------
-    long long dm[SYNC_V];
-    long long tm = 0;
+    // ---- 5. CP-length moving average of M (float32), minus one -----------------------------
+    float pm[SYNC_V];
+    F3 msum = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
       const int i = SYNC_V * tid + j;
-      const float mold = ms[sync_lp(p.HM + i - p.CP)];
-      tm += q40_from_float(Mv[j]) - q40_from_float(mold);
-      dm[j] = tm;
+      msum.a += Mv[j] - ms[sync_lp(HM + i - CP)];
+      pm[j] = msum.a;
     }
-    long long totm;
-    const long long em = block_excl_scan_add<long long>(tm, sc_i64, &totm);
+    F3 manc = {0.f, 0.f, 0.f};
+    for (int m = -CP + tid; m < 0; m += SYNC_THREADS) manc.a += ms[sync_lp(HM + m)];
+    F3 mex, mtot, mach;
+    block_scan3_sum3(msum, manc, sc_f32, &mex, &mtot, &mach);
     float u[SYNC_V];
 #pragma unroll
-    for (int j = 0; j < SYNC_V; j++) {
-      const double s = q40_to_double(wm + em + dm[j]);
-      const float mbar = (float)(s * (double)p.tapcp);
-      u[j] = mbar + (-1.0f);
-    }
-    wm += totm;
+    for (int j = 0; j < SYNC_V; j++) u[j] = (mach.a + mex.a + pm[j]) * inv_cp - 1.0f;
 
     if (owned) {
-      // ---- 6. per-tile summary of the detector's running average + candidates --------------
-      int nv = 0;  // valid (in-stream) samples of this thread
-      unsigned cmask = 0;
-      Aff f;
-      f.A = 1.0;
-      f.b = 0.0;
+      // ---- 6. tile summary of the detector's running average; float32 pre-selection --------------
+      int nv = 0;
+      unsigned amask = 0;  // approximate candidates
+      float floc = 0.f;
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
         const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
         if (n < p.nsamples) {
           nv++;
-          f.A = f.A * p.decay;
-          f.b = (double)p.alpha * (double)u[j] + p.decay * f.b;
-          if (u[j] > p.cand_thr) cmask |= 1u << j;
-          if (p.metric_tap) p.metric_tap[n] = u[j];
+          floc = fmaf(floc, decay_f, p.alpha * u[j]);
+          if (u[j] > p.cand_thr - SYNC_GUARD) amask |= 1u << j;
         }
       }
-      // inclusive scan of the affine maps across the block
-      Aff inc = f;
-      {
-        const int lane = lane_id(), w = wave_id();
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-          Aff o;
-          o.A = __shfl_up(inc.A, d, WAVE);
-          o.b = __shfl_up(inc.b, d, WAVE);
-          if (lane >= d) inc = aff_then(o, inc);
-        }
-        if (lane == WAVE - 1) {
-          sc_f64[2 * w] = inc.A;
-          sc_f64[2 * w + 1] = inc.b;
-        }
+      const bool full_tile = t0 + (uint64_t)T <= p.nsamples;
+      float wgt = wfull;
+      if (!full_tile) {
+        // samples after this thread's in the (short) last tile
+        const int64_t tv = (int64_t)(p.nsamples - t0);
+        const int64_t after = tv - (int64_t)(SYNC_V * tid + nv);
+        wgt = (float)pow(p.decay, (double)(after > 0 ? after : 0));
       }
-      const int anyc = __syncthreads_or(cmask != 0);
-      Aff pre;  // map of everything before this thread in the tile
-      pre.A = 1.0;
-      pre.b = 0.0;
-      Aff tot = pre;
-      {
-        const int w = wave_id();
-        for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
-          Aff g;
-          g.A = sc_f64[2 * i];
-          g.b = sc_f64[2 * i + 1];
-          if (i < w) pre = aff_then(pre, g);
-          tot = aff_then(tot, g);
-        }
-        // exclusive within the wave: inc = pre_wave_lanes then f  =>  strip f via shuffle
-        Aff prev;
-        prev.A = __shfl_up(inc.A, 1, WAVE);
-        prev.b = __shfl_up(inc.b, 1, WAVE);
-        if (lane_id() == 0) {
-          prev.A = 1.0;
-          prev.b = 0.0;
-        }
-        pre = aff_then(pre, prev);
-      }
+      F3 bsum = {floc * wgt, 0.f, 0.f}, z3 = {0.f, 0.f, 0.f}, d0, d1_, bs;
+      if (p.exact_all) amask = (nv == SYNC_V) ? 0xFFu : ((1u << nv) - 1u);
       if (tid == 0) {
-        p.tile_B[tile] = tot.b;
-        if (!anyc) p.tile_npieces[tile] = 0;
+        rng[0] = T;
+        rng[1] = -1;
       }
+      block_scan3_sum3(z3, bsum, sc_f32, &d0, &d1_, &bs);  // (contains the barriers that publish rng[])
+      if (amask) {
+        atomicMin(&rng[0], SYNC_V * tid + __ffs(amask) - 1);
+        atomicMax(&rng[1], SYNC_V * tid + 31 - __clz(amask));
+      }
+      if (tid == 0) p.tile_B[tile] = (double)bs.a;
+      __syncthreads();
+      const int amin = rng[0], bmax = rng[1];
+      const bool anyc = bmax >= 0;
+      if (!anyc) {
+        if (tid == 0) p.tile_npieces[tile] = 0;
+      } else {
+        // ---- 7. fixed-point re-evaluation of [amin, bmax] (normative arithmetic) ------------------
+        c32* Pe = xs + sync_lp(p.HX) + 8;       // scratch: the x tile is dead (history already saved)
+        sync_exact_range(ys, me, ue, Pe, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid, p.tapcp);
 
-      if (anyc) {
-        // ---- 7. candidate pieces: maximal runs of u > theta inside the tile -----------------
+        // ---- 8. candidates: maximal runs of (exact) u > theta inside the tile ----------------------
+        unsigned cmask = 0;
+#pragma unroll
+        for (int j = 0; j < SYNC_V; j++) {
+          const int i = SYNC_V * tid + j;
+          if (j < nv && i >= amin && i <= bmax) {
+            const float ux = ue[i - amin];
+            u[j] = ux;
+            if (ux > p.cand_thr) cmask |= 1u << j;
+            if (p.metric_tap) p.metric_tap[t0 + (uint64_t)i] = ux;
+          }
+        }
+        // running average before each sample of this thread (zero-initialised at the tile start)
+        Aff f;
+        f.A = 1.0;
+        f.b = 0.0;
+#pragma unroll
+        for (int j = 0; j < SYNC_V; j++)
+          if (j < nv) {
+            f.A = f.A * p.decay;
+            f.b = (double)p.alpha * (double)u[j] + p.decay * f.b;
+          }
+        Aff inc = f;
+        {
+          const int lane = lane_id(), w = wave_id();
+#pragma unroll
+          for (int d = 1; d < WAVE; d <<= 1) {
+            Aff o;
+            o.A = __shfl_up(inc.A, d, WAVE);
+            o.b = __shfl_up(inc.b, d, WAVE);
+            if (lane >= d) inc = aff_then(o, inc);
+          }
+          if (lane == WAVE - 1) {
+            sc_f64[2 * w] = inc.A;
+            sc_f64[2 * w + 1] = inc.b;
+          }
+        }
         cm[tid] = (unsigned char)cmask;
         __syncthreads();
+        Aff pre;
+        pre.A = 1.0;
+        pre.b = 0.0;
+        {
+          const int w = wave_id();
+          for (int i = 0; i < w; i++) {
+            Aff g;
+            g.A = sc_f64[2 * i];
+            g.b = sc_f64[2 * i + 1];
+            pre = aff_then(pre, g);
+          }
+          Aff prev;
+          prev.A = __shfl_up(inc.A, 1, WAVE);
+          prev.b = __shfl_up(inc.b, 1, WAVE);
+          if (lane_id() == 0) {
+            prev.A = 1.0;
+            prev.b = 0.0;
+          }
+          pre = aff_then(pre, prev);
+        }
         const unsigned prevbit = (tid > 0) ? ((cm[tid - 1] >> 7) & 1u) : 0u;
         const unsigned nextbit = (tid < SYNC_THREADS - 1) ? (cm[tid + 1] & 1u) : 0u;
         const unsigned ext = (cmask << 1) | prevbit;           // bit j+1 = cand[j], bit 0 = cand[-1]
@@ -355,8 +604,11 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
         const int nstart_before = pex >> 16, ncand_before = pex & 0xFFFF;
         const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
         if (tid == 0) {
-          unsigned long long basev = atomicAdd(p.cand_count, (unsigned long long)ncand);
-          unsigned long long basep = atomicAdd(p.piece_count, (unsigned long long)npieces);
+          unsigned long long basev = 0, basep = 0;
+          if (ncand > 0) {
+            basev = atomicAdd(p.cand_count, (unsigned long long)ncand);
+            basep = atomicAdd(p.piece_count, (unsigned long long)npieces);
+          }
           bc[0] = basev;
           bc[1] = basep;
           if (basev + (unsigned long long)ncand > p.cand_cap || basep + (unsigned long long)npieces > p.piece_cap)
@@ -366,12 +618,13 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
         const unsigned long long basev = bc[0], basep = bc[1];
         const bool fits = (basev + (unsigned long long)ncand <= p.cand_cap) &&
                           (basep + (unsigned long long)npieces <= p.piece_cap);
-        if (fits) {
+        if (fits && ncand > 0) {
           double a_loc = pre.b;  // zero-init average just before this thread's first sample
           int so = nstart_before, co = ncand_before;
 #pragma unroll
           for (int j = 0; j < SYNC_V; j++) {
-            const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
+            const int i = SYNC_V * tid + j;
+            const uint64_t n = t0 + (uint64_t)i;
             if ((startmask >> j) & 1u) {
               SyncPiece* pc = p.pieces + basep + so;
               pc->start = n;
@@ -381,7 +634,7 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
             }
             if ((cmask >> j) & 1u) {
               p.cand_u[basev + co] = u[j];
-              p.cand_P[basev + co] = Pv[j];
+              p.cand_P[basev + co] = Pe[i - amin];
               co++;
             }
             if ((endmask >> j) & 1u) p.pieces[basep + so - 1].end = n;
@@ -396,50 +649,35 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync(SyncParams p) {
     }
     __syncthreads();
 
-    // ---- 8. slide the histories ---------------------------------------------------------------
+    // ---- 9. slide the y and M histories ---------------------------------------------------------
     if (tile + 1 < tile_own1) {
-      for (int off = 0; off < p.HX; off += T) {
+      for (int off = 0; off < HY; off += T) {
         c32 v[SYNC_V];
 #pragma unroll
         for (int r = 0; r < SYNC_V; r++) {
           const int i = off + tid + r * SYNC_THREADS;
-          if (i < p.HX && i < off + T) v[r] = xs[sync_lp(i + T)];
+          if (i < HY && i < off + T) v[r] = ys[sync_lp(i + T)];
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SYNC_V; r++) {
           const int i = off + tid + r * SYNC_THREADS;
-          if (i < p.HX && i < off + T) xs[sync_lp(i)] = v[r];
+          if (i < HY && i < off + T) ys[sync_lp(i)] = v[r];
         }
         __syncthreads();
       }
-      for (int off = 0; off < p.HY; off += T) {
-        c32 v[SYNC_V];
-#pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
-          if (i < p.HY && i < off + T) v[r] = ys[sync_lp(i + T)];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
-          if (i < p.HY && i < off + T) ys[sync_lp(i)] = v[r];
-        }
-        __syncthreads();
-      }
-      for (int off = 0; off < p.HM; off += T) {
+      for (int off = 0; off < HM; off += T) {
         float v[SYNC_V];
 #pragma unroll
         for (int r = 0; r < SYNC_V; r++) {
           const int i = off + tid + r * SYNC_THREADS;
-          if (i < p.HM && i < off + T) v[r] = ms[sync_lp(i + T)];
+          if (i < HM && i < off + T) v[r] = ms[sync_lp(i + T)];
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SYNC_V; r++) {
           const int i = off + tid + r * SYNC_THREADS;
-          if (i < p.HM && i < off + T) ms[sync_lp(i)] = v[r];
+          if (i < HM && i < off + T) ms[sync_lp(i)] = v[r];
         }
         __syncthreads();
       }
