@@ -125,9 +125,10 @@ struct F3 {
   float a, b, c;
 };
 
-// Block-wide (4 waves) exclusive scan of three floats + block sum of three more, one barrier pair.
-// scratch: 4 waves x 6 floats.
-__device__ __forceinline__ void block_scan3_sum3(F3 v, F3 s, float* scratch, F3* excl, F3* total, F3* sum) {
+// Block-wide (4 waves) scans / sums.  Each call has ONE barrier; `scratch` must not be a region
+// another call of the same tile iteration used since the last-but-one barrier (callers rotate
+// three regions).
+__device__ __forceinline__ void block_scan3_sum3(F3 v, F3 s, float* scratch, F3* excl, F3* sum) {
   const int lane = lane_id(), w = wave_id();
   F3 inc;
   inc.a = wave_incl_scan_f32(v.a);
@@ -146,27 +147,39 @@ __device__ __forceinline__ void block_scan3_sum3(F3 v, F3 s, float* scratch, F3*
     scratch[w * 6 + 5] = rs.c;
   }
   __syncthreads();
-  F3 base = {0.f, 0.f, 0.f}, tot = {0.f, 0.f, 0.f}, sm = {0.f, 0.f, 0.f};
+  F3 base = {0.f, 0.f, 0.f}, sm = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
-    const float a = scratch[i * 6 + 0], b = scratch[i * 6 + 1], c = scratch[i * 6 + 2];
     if (i < w) {
-      base.a += a;
-      base.b += b;
-      base.c += c;
+      base.a += scratch[i * 6 + 0];
+      base.b += scratch[i * 6 + 1];
+      base.c += scratch[i * 6 + 2];
     }
-    tot.a += a;
-    tot.b += b;
-    tot.c += c;
     sm.a += scratch[i * 6 + 3];
     sm.b += scratch[i * 6 + 4];
     sm.c += scratch[i * 6 + 5];
   }
-  __syncthreads();
   excl->a = base.a + inc.a - v.a;
   excl->b = base.b + inc.b - v.b;
   excl->c = base.c + inc.c - v.c;
-  *total = tot;
+  *sum = sm;
+}
+__device__ __forceinline__ void block_scan1_sum1(float v, float s, float* scratch, float* excl, float* sum) {
+  const int lane = lane_id(), w = wave_id();
+  const float inc = wave_incl_scan_f32(v);
+  const float rs = wave_incl_scan_f32(s);
+  if (lane == WAVE - 1) {
+    scratch[w * 2 + 0] = inc;
+    scratch[w * 2 + 1] = rs;
+  }
+  __syncthreads();
+  float base = 0.f, sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
+    if (i < w) base += scratch[i * 2 + 0];
+    sm += scratch[i * 2 + 1];
+  }
+  *excl = base + inc - v;
   *sum = sm;
 }
 
@@ -283,8 +296,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   int* sc_i32 = reinterpret_cast<int*>(misc + 256);            // 5 entries
   unsigned char* cm = misc + 320;                               // 256 candidate masks
   unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 576);  // 2 broadcast words
-  float* sc_f32 = reinterpret_cast<float*>(misc + 608);        // 24 floats
-  int* rng = reinterpret_cast<int*>(misc + 720);               // [0] amin, [1] bmax
+  float* scA = reinterpret_cast<float*>(misc + 608);           // 24 floats
+  float* scB = reinterpret_cast<float*>(misc + 704);           // 8 floats
+  float* scC = reinterpret_cast<float*>(misc + 736);           // 4 floats
+  int* rng = reinterpret_cast<int*>(misc + 752);               // [0] amin, [1] bmax
 
   const uint64_t seg = blockIdx.x;
   const uint64_t tile_own0 = seg * (uint64_t)p.tiles_per_seg;
@@ -305,26 +320,43 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     if (n >= 0 && (uint64_t)n < p.nsamples) v = p.x[n];
     xs[sync_lp(i)] = v;
   }
-  for (int i = tid; i < HY; i += SYNC_THREADS) ys[sync_lp(i)] = mk(0.f, 0.f);
-  for (int i = tid; i < HM; i += SYNC_THREADS) ms[sync_lp(i)] = 0.0f;
+  // the per-tile slide moves [T, T+H) to [0, H): park the zero history where the first slide picks it up
+  for (int i = tid; i < HY; i += SYNC_THREADS) ys[sync_lp(i + T)] = mk(0.f, 0.f);
+  for (int i = tid; i < HM; i += SYNC_THREADS) ms[sync_lp(i + T)] = 0.0f;
   const bool x_al16 = ((uintptr_t)p.x & 15) == 0;
   const bool y_al16 = ((uintptr_t)p.y & 15) == 0;
   // weight of this thread's 8 samples in the tile summary of the detector average
   const float decay_f = (float)p.decay;
   const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
+  // LDS indices of this thread's 8 consecutive samples (HX, HY, D multiples of 8: lp(8g + r) = 9g + r)
+  const int gb = sync_lp(p.HX + SYNC_V * tid - 8);
+  const int yb = sync_lp(HY + SYNC_V * tid), yb1 = sync_lp(HY - D + SYNC_V * tid), yb2 = sync_lp(HY - 2 * D + SYNC_V * tid);
+  float4 xpre[SYNC_V / 2];
+  bool have_pre = false;
   __syncthreads();
 
   for (uint64_t tile = tile_first; tile < tile_own1; tile++) {
     const uint64_t t0 = tile * (uint64_t)T;
     const int64_t t0s = (int64_t)t0;
     const bool owned = tile >= tile_own0;
+    const bool masked = warm && (t0s < qvalid + D);  // some sample of the tile lacks real history
 
-    // ---- 1. load the tile of x into LDS (coalesced, 16 B per lane when aligned) ---
-    if (x_al16 && t0 + (uint64_t)T <= p.nsamples) {
-      const float4* src = reinterpret_cast<const float4*>(p.x + t0);
+    // ---- 1. x tile into LDS (prefetched during the previous tile's filter when possible);
+    //         slide the y and M histories.  All hazards are covered by the barriers of the
+    //         previous iteration (k_sync).
+    if (have_pre) {
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) {
         const int pi = tid + r * SYNC_THREADS;  // pair index
+        const int li = sync_lp(p.HX + 2 * pi);
+        xs[li] = mk(xpre[r].x, xpre[r].y);
+        xs[li + 1] = mk(xpre[r].z, xpre[r].w);
+      }
+    } else if (x_al16 && t0 + (uint64_t)T <= p.nsamples) {
+      const float4* src = reinterpret_cast<const float4*>(p.x + t0);
+#pragma unroll
+      for (int r = 0; r < SYNC_V / 2; r++) {
+        const int pi = tid + r * SYNC_THREADS;
         const float4 v = src[pi];
         const int li = sync_lp(p.HX + 2 * pi);
         xs[li] = mk(v.x, v.y);
@@ -340,16 +372,42 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         xs[sync_lp(p.HX + i)] = v;
       }
     }
-    __syncthreads();
+    if (HY <= T) {
+      for (int i = tid; i < HY; i += SYNC_THREADS) ys[sync_lp(i)] = ys[sync_lp(i + T)];
+    } else {
+      for (int off = 0; off < HY; off += T) {  // overlapping ranges: chunk by chunk
+        c32 v[SYNC_V];
+#pragma unroll
+        for (int r = 0; r < SYNC_V; r++) {
+          const int i = off + tid + r * SYNC_THREADS;
+          if (i < HY && i < off + T) v[r] = ys[sync_lp(i + T)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SYNC_V; r++) {
+          const int i = off + tid + r * SYNC_THREADS;
+          if (i < HY && i < off + T) ys[sync_lp(i)] = v[r];
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < HM; i += SYNC_THREADS) ms[sync_lp(i)] = ms[sync_lp(i + T)];  // HM <= T (checked by the host)
+    __syncthreads();  // B1
+
+    // prefetch the next tile of x; its latency hides behind the filter
+    have_pre = false;
+    if (tile + 1 < tile_own1 && x_al16 && t0 + 2ull * T <= p.nsamples) {
+      const float4* src = reinterpret_cast<const float4*>(p.x + t0 + T);
+#pragma unroll
+      for (int r = 0; r < SYNC_V / 2; r++) xpre[r] = src[tid + r * SYNC_THREADS];
+      have_pre = true;
+    }
 
     // ---- 2. channel filter: one fmaf chain per output, taps in order ----------------
     {
       c32 acc[SYNC_V];
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) acc[j] = mk(0.f, 0.f);
-      // HX and 8*tid are multiples of 8, so a padded index splits into a group base plus a small
-      // compile-time offset: lp(8g + r) = 9g + r.  gb = padded index of the group below output 0.
-      const int gb = sync_lp(p.HX + SYNC_V * tid - 8);
       // U blocks of 8 taps per iteration.  Inside the body the sliding window is renamed by the
       // compiler (static indices, no moves); it is re-read from LDS at the top of every iteration so
       // that nothing but one index is carried around the loop.  The taps of an iteration sit in SGPRs.
@@ -383,11 +441,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         }
         gw -= 9 * U;
       }
-      const int yb0 = sync_lp(HY + SYNC_V * tid);
 #pragma unroll
-      for (int j = 0; j < SYNC_V; j++) ys[yb0 + j] = acc[j];
+      for (int j = 0; j < SYNC_V; j++) ys[yb + j] = acc[j];
     }
-    __syncthreads();
+    __syncthreads();  // B2
     // x history for the next tile: [T, T+HX) -> [0, HX) (disjoint, T >= HX); the rest of xs is scratch from here on
     for (int i = tid; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
 
@@ -415,50 +472,69 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     // ---- 4. float32 Schmidl-Cox sums, anchored at the tile start --------------------------
     float pfr[SYNC_V], pfi[SYNC_V], pfe[SYNC_V];
     F3 tsum = {0.f, 0.f, 0.f};
-    const int yb = sync_lp(HY + SYNC_V * tid), yb1 = sync_lp(HY - D + SYNC_V * tid), yb2 = sync_lp(HY - 2 * D + SYNC_V * tid);
-    const int mb = sync_lp(HM + SYNC_V * tid);
-#pragma unroll
-    for (int j = 0; j < SYNC_V; j++) {
-      const int i = SYNC_V * tid + j;
-      const int64_t n = t0s + i;
-      const c32 a = ys[yb + j];
-      const c32 d1 = ys[yb1 + j];
-      const c32 d2 = ys[yb2 + j];
-      float nr = 0.f, ni = 0.f, ne = 0.f, orr = 0.f, oi = 0.f, oe = 0.f;
-      if (n >= qvalid) {
-        nr = fmaf(a.re, d1.re, a.im * d1.im);
-        ni = fmaf(a.im, d1.re, -(a.re * d1.im));
-        ne = fmaf(a.re, a.re, a.im * a.im);
-      }
-      if (n >= qvalid + D) {
-        orr = fmaf(d1.re, d2.re, d1.im * d2.im);
-        oi = fmaf(d1.im, d2.re, -(d1.re * d2.im));
-        oe = fmaf(d1.re, d1.re, d1.im * d1.im);
-      }
-      tsum.a += nr - orr;
-      tsum.b += ni - oi;
-      tsum.c += ne - oe;
-      pfr[j] = tsum.a;
-      pfi[j] = tsum.b;
-      pfe[j] = tsum.c;
-    }
-    // anchor: the window sums at the sample before the tile, summed afresh from the history
     F3 anc = {0.f, 0.f, 0.f};
-    for (int m = -D + tid; m < 0; m += SYNC_THREADS) {
-      if (t0s + m >= qvalid) {
+    if (!masked) {
+#pragma unroll
+      for (int j = 0; j < SYNC_V; j++) {
+        const c32 a = ys[yb + j];
+        const c32 d1 = ys[yb1 + j];
+        const c32 d2 = ys[yb2 + j];
+        tsum.a += fmaf(a.re, d1.re, a.im * d1.im) - fmaf(d1.re, d2.re, d1.im * d2.im);
+        tsum.b += fmaf(a.im, d1.re, -(a.re * d1.im)) - fmaf(d1.im, d2.re, -(d1.re * d2.im));
+        tsum.c += fmaf(a.re, a.re, a.im * a.im) - fmaf(d1.re, d1.re, d1.im * d1.im);
+        pfr[j] = tsum.a;
+        pfi[j] = tsum.b;
+        pfe[j] = tsum.c;
+      }
+      // anchor: the window sums at the sample before the tile, summed afresh from the history
+      for (int m = -D + tid; m < 0; m += SYNC_THREADS) {
         const c32 a = ys[sync_lp(HY + m)];
         const c32 d1 = ys[sync_lp(HY + m - D)];
         anc.a += fmaf(a.re, d1.re, a.im * d1.im);
         anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
         anc.c += fmaf(a.re, a.re, a.im * a.im);
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SYNC_V; j++) {
+        const int64_t n = t0s + SYNC_V * tid + j;
+        const c32 a = ys[yb + j];
+        const c32 d1 = ys[yb1 + j];
+        const c32 d2 = ys[yb2 + j];
+        float nr = 0.f, ni = 0.f, ne = 0.f, orr = 0.f, oi = 0.f, oe = 0.f;
+        if (n >= qvalid) {
+          nr = fmaf(a.re, d1.re, a.im * d1.im);
+          ni = fmaf(a.im, d1.re, -(a.re * d1.im));
+          ne = fmaf(a.re, a.re, a.im * a.im);
+        }
+        if (n >= qvalid + D) {
+          orr = fmaf(d1.re, d2.re, d1.im * d2.im);
+          oi = fmaf(d1.im, d2.re, -(d1.re * d2.im));
+          oe = fmaf(d1.re, d1.re, d1.im * d1.im);
+        }
+        tsum.a += nr - orr;
+        tsum.b += ni - oi;
+        tsum.c += ne - oe;
+        pfr[j] = tsum.a;
+        pfi[j] = tsum.b;
+        pfe[j] = tsum.c;
+      }
+      for (int m = -D + tid; m < 0; m += SYNC_THREADS) {
+        if (t0s + m >= qvalid) {
+          const c32 a = ys[sync_lp(HY + m)];
+          const c32 d1 = ys[sync_lp(HY + m - D)];
+          anc.a += fmaf(a.re, d1.re, a.im * d1.im);
+          anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
+          anc.c += fmaf(a.re, a.re, a.im * a.im);
+        }
+      }
     }
-    F3 ex3, tot3, anch;
-    block_scan3_sum3(tsum, anc, sc_f32, &ex3, &tot3, &anch);
+    F3 ex3, anch;
+    block_scan3_sum3(tsum, anc, scA, &ex3, &anch);  // B3
     float Mv[SYNC_V];
+    const int mb = sync_lp(HM + SYNC_V * tid);
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
-      const int64_t n = t0s + SYNC_V * tid + j;
       const float pre = anch.a + ex3.a + pfr[j];
       const float pim = anch.b + ex3.b + pfi[j];
       const float r = anch.c + ex3.c + pfe[j];
@@ -466,222 +542,190 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       const float den = r * r;
       float m = (den > 0.0f) ? __fdividef(num, den) : 0.0f;
       if (!(m <= 1024.0f)) m = 1024.0f;
-      if (n < mvalid) m = 0.0f;
+      if (masked && (t0s + SYNC_V * tid + j < mvalid)) m = 0.0f;
       Mv[j] = m;
       ms[mb + j] = m;
     }
-    __syncthreads();
+    __syncthreads();  // B4
 
     // ---- 5. CP-length moving average of M (float32), minus one -----------------------------
     float pm[SYNC_V];
-    F3 msum = {0.f, 0.f, 0.f};
+    float msum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SYNC_V; j++) {
+      msum += Mv[j] - ms[sync_lp(HM + SYNC_V * tid + j - CP)];
+      pm[j] = msum;
+    }
+    float manc = 0.f;
+    for (int m = -CP + tid; m < 0; m += SYNC_THREADS) manc += ms[sync_lp(HM + m)];
+    float mex, mach;
+    block_scan1_sum1(msum, manc, scB, &mex, &mach);  // B5
+    if (!owned) continue;  // warm-up tile: only the histories matter
+
+    float u[SYNC_V];
+#pragma unroll
+    for (int j = 0; j < SYNC_V; j++) u[j] = (mach + mex + pm[j]) * inv_cp - 1.0f;
+
+    // ---- 6. tile summary of the detector's running average; float32 pre-selection --------------
+    int nv = 0;
+    unsigned amask = 0;  // approximate candidates
+    float floc = 0.f;
+#pragma unroll
+    for (int j = 0; j < SYNC_V; j++) {
+      const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
+      if (n < p.nsamples) {
+        nv++;
+        floc = fmaf(floc, decay_f, p.alpha * u[j]);
+        if (u[j] > p.cand_thr - SYNC_GUARD) amask |= 1u << j;
+      }
+    }
+    float wgt = wfull;
+    if (t0 + (uint64_t)T > p.nsamples) {
+      // the (short) last tile: weight by the samples that follow this thread's
+      const int64_t after = (int64_t)(p.nsamples - t0) - (int64_t)(SYNC_V * tid + nv);
+      wgt = (float)pow(p.decay, (double)(after > 0 ? after : 0));
+    }
+    if (p.exact_all) amask = (1u << nv) - 1u;
+    {
+      const float bw = wave_incl_scan_f32(floc * wgt);
+      if (lane_id() == WAVE - 1) scC[wave_id()] = bw;
+    }
+    const int anyc = __syncthreads_or(amask != 0);  // B6
+    if (tid == 0) {
+      p.tile_B[tile] = (double)((scC[0] + scC[1]) + (scC[2] + scC[3]));
+      if (!anyc) p.tile_npieces[tile] = 0;
+    }
+    if (!anyc) continue;
+
+    // ================= rare path: something near the threshold in this tile =================
+    if (tid == 0) {
+      rng[0] = T;
+      rng[1] = -1;
+    }
+    __syncthreads();
+    if (amask) {
+      atomicMin(&rng[0], SYNC_V * tid + __ffs(amask) - 1);
+      atomicMax(&rng[1], SYNC_V * tid + 31 - __clz(amask));
+    }
+    __syncthreads();
+    const int amin = rng[0], bmax = rng[1];
+    // ---- 7. fixed-point re-evaluation of [amin, bmax] (normative arithmetic) ------------------
+    c32* Pe = xs + sync_lp(p.HX) + 8;  // scratch: the x tile is dead (history already saved)
+    sync_exact_range(ys, me, ue, Pe, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid, p.tapcp);
+
+    // ---- 8. candidates: maximal runs of (exact) u > theta inside the tile ----------------------
+    unsigned cmask = 0;
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
       const int i = SYNC_V * tid + j;
-      msum.a += Mv[j] - ms[sync_lp(HM + i - CP)];
-      pm[j] = msum.a;
+      if (j < nv && i >= amin && i <= bmax) {
+        const float ux = ue[i - amin];
+        u[j] = ux;
+        if (ux > p.cand_thr) cmask |= 1u << j;
+        if (p.metric_tap) p.metric_tap[t0 + (uint64_t)i] = ux;
+      }
     }
-    F3 manc = {0.f, 0.f, 0.f};
-    for (int m = -CP + tid; m < 0; m += SYNC_THREADS) manc.a += ms[sync_lp(HM + m)];
-    F3 mex, mtot, mach;
-    block_scan3_sum3(msum, manc, sc_f32, &mex, &mtot, &mach);
-    float u[SYNC_V];
+    // running average before each sample of this thread (zero-initialised at the tile start)
+    Aff f;
+    f.A = 1.0;
+    f.b = 0.0;
 #pragma unroll
-    for (int j = 0; j < SYNC_V; j++) u[j] = (mach.a + mex.a + pm[j]) * inv_cp - 1.0f;
-
-    if (owned) {
-      // ---- 6. tile summary of the detector's running average; float32 pre-selection --------------
-      int nv = 0;
-      unsigned amask = 0;  // approximate candidates
-      float floc = 0.f;
-#pragma unroll
-      for (int j = 0; j < SYNC_V; j++) {
-        const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
-        if (n < p.nsamples) {
-          nv++;
-          floc = fmaf(floc, decay_f, p.alpha * u[j]);
-          if (u[j] > p.cand_thr - SYNC_GUARD) amask |= 1u << j;
-        }
+    for (int j = 0; j < SYNC_V; j++)
+      if (j < nv) {
+        f.A = f.A * p.decay;
+        f.b = (double)p.alpha * (double)u[j] + p.decay * f.b;
       }
-      const bool full_tile = t0 + (uint64_t)T <= p.nsamples;
-      float wgt = wfull;
-      if (!full_tile) {
-        // samples after this thread's in the (short) last tile
-        const int64_t tv = (int64_t)(p.nsamples - t0);
-        const int64_t after = tv - (int64_t)(SYNC_V * tid + nv);
-        wgt = (float)pow(p.decay, (double)(after > 0 ? after : 0));
-      }
-      F3 bsum = {floc * wgt, 0.f, 0.f}, z3 = {0.f, 0.f, 0.f}, d0, d1_, bs;
-      if (p.exact_all) amask = (nv == SYNC_V) ? 0xFFu : ((1u << nv) - 1u);
-      if (tid == 0) {
-        rng[0] = T;
-        rng[1] = -1;
-      }
-      block_scan3_sum3(z3, bsum, sc_f32, &d0, &d1_, &bs);  // (contains the barriers that publish rng[])
-      if (amask) {
-        atomicMin(&rng[0], SYNC_V * tid + __ffs(amask) - 1);
-        atomicMax(&rng[1], SYNC_V * tid + 31 - __clz(amask));
-      }
-      if (tid == 0) p.tile_B[tile] = (double)bs.a;
-      __syncthreads();
-      const int amin = rng[0], bmax = rng[1];
-      const bool anyc = bmax >= 0;
-      if (!anyc) {
-        if (tid == 0) p.tile_npieces[tile] = 0;
-      } else {
-        // ---- 7. fixed-point re-evaluation of [amin, bmax] (normative arithmetic) ------------------
-        c32* Pe = xs + sync_lp(p.HX) + 8;       // scratch: the x tile is dead (history already saved)
-        sync_exact_range(ys, me, ue, Pe, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid, p.tapcp);
-
-        // ---- 8. candidates: maximal runs of (exact) u > theta inside the tile ----------------------
-        unsigned cmask = 0;
+    Aff inc = f;
+    {
+      const int lane = lane_id(), w = wave_id();
 #pragma unroll
-        for (int j = 0; j < SYNC_V; j++) {
-          const int i = SYNC_V * tid + j;
-          if (j < nv && i >= amin && i <= bmax) {
-            const float ux = ue[i - amin];
-            u[j] = ux;
-            if (ux > p.cand_thr) cmask |= 1u << j;
-            if (p.metric_tap) p.metric_tap[t0 + (uint64_t)i] = ux;
-          }
-        }
-        // running average before each sample of this thread (zero-initialised at the tile start)
-        Aff f;
-        f.A = 1.0;
-        f.b = 0.0;
-#pragma unroll
-        for (int j = 0; j < SYNC_V; j++)
-          if (j < nv) {
-            f.A = f.A * p.decay;
-            f.b = (double)p.alpha * (double)u[j] + p.decay * f.b;
-          }
-        Aff inc = f;
-        {
-          const int lane = lane_id(), w = wave_id();
-#pragma unroll
-          for (int d = 1; d < WAVE; d <<= 1) {
-            Aff o;
-            o.A = __shfl_up(inc.A, d, WAVE);
-            o.b = __shfl_up(inc.b, d, WAVE);
-            if (lane >= d) inc = aff_then(o, inc);
-          }
-          if (lane == WAVE - 1) {
-            sc_f64[2 * w] = inc.A;
-            sc_f64[2 * w + 1] = inc.b;
-          }
-        }
-        cm[tid] = (unsigned char)cmask;
-        __syncthreads();
-        Aff pre;
-        pre.A = 1.0;
-        pre.b = 0.0;
-        {
-          const int w = wave_id();
-          for (int i = 0; i < w; i++) {
-            Aff g;
-            g.A = sc_f64[2 * i];
-            g.b = sc_f64[2 * i + 1];
-            pre = aff_then(pre, g);
-          }
-          Aff prev;
-          prev.A = __shfl_up(inc.A, 1, WAVE);
-          prev.b = __shfl_up(inc.b, 1, WAVE);
-          if (lane_id() == 0) {
-            prev.A = 1.0;
-            prev.b = 0.0;
-          }
-          pre = aff_then(pre, prev);
-        }
-        const unsigned prevbit = (tid > 0) ? ((cm[tid - 1] >> 7) & 1u) : 0u;
-        const unsigned nextbit = (tid < SYNC_THREADS - 1) ? (cm[tid + 1] & 1u) : 0u;
-        const unsigned ext = (cmask << 1) | prevbit;           // bit j+1 = cand[j], bit 0 = cand[-1]
-        const unsigned startmask = cmask & ~ext & 0xFFu;       // cand[j] && !cand[j-1]
-        const unsigned extn = (cmask >> 1) | (nextbit << 7);   // bit j = cand[j+1]
-        const unsigned endmask = cmask & ~extn & 0xFFu;        // cand[j] && !cand[j+1]
-        const int packed = (__popc(startmask) << 16) | __popc(cmask);
-        int ptot;
-        const int pex = block_excl_scan_add<int>(packed, sc_i32, &ptot);
-        const int nstart_before = pex >> 16, ncand_before = pex & 0xFFFF;
-        const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
-        if (tid == 0) {
-          unsigned long long basev = 0, basep = 0;
-          if (ncand > 0) {
-            basev = atomicAdd(p.cand_count, (unsigned long long)ncand);
-            basep = atomicAdd(p.piece_count, (unsigned long long)npieces);
-          }
-          bc[0] = basev;
-          bc[1] = basep;
-          if (basev + (unsigned long long)ncand > p.cand_cap || basep + (unsigned long long)npieces > p.piece_cap)
-            atomicOr(p.overflow, 1u);
-        }
-        __syncthreads();
-        const unsigned long long basev = bc[0], basep = bc[1];
-        const bool fits = (basev + (unsigned long long)ncand <= p.cand_cap) &&
-                          (basep + (unsigned long long)npieces <= p.piece_cap);
-        if (fits && ncand > 0) {
-          double a_loc = pre.b;  // zero-init average just before this thread's first sample
-          int so = nstart_before, co = ncand_before;
-#pragma unroll
-          for (int j = 0; j < SYNC_V; j++) {
-            const int i = SYNC_V * tid + j;
-            const uint64_t n = t0 + (uint64_t)i;
-            if ((startmask >> j) & 1u) {
-              SyncPiece* pc = p.pieces + basep + so;
-              pc->start = n;
-              pc->val_off = basev + (unsigned long long)co;
-              pc->bloc = a_loc;
-              so++;
-            }
-            if ((cmask >> j) & 1u) {
-              p.cand_u[basev + co] = u[j];
-              p.cand_P[basev + co] = Pe[i - amin];
-              co++;
-            }
-            if ((endmask >> j) & 1u) p.pieces[basep + so - 1].end = n;
-            if (j < nv) a_loc = (double)p.alpha * (double)u[j] + p.decay * a_loc;
-          }
-        }
-        if (tid == 0) {
-          p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
-          p.tile_first[tile] = basep;
-        }
+      for (int d = 1; d < WAVE; d <<= 1) {
+        Aff o;
+        o.A = __shfl_up(inc.A, d, WAVE);
+        o.b = __shfl_up(inc.b, d, WAVE);
+        if (lane >= d) inc = aff_then(o, inc);
       }
+      if (lane == WAVE - 1) {
+        sc_f64[2 * w] = inc.A;
+        sc_f64[2 * w + 1] = inc.b;
+      }
+    }
+    cm[tid] = (unsigned char)cmask;
+    __syncthreads();
+    Aff pre;
+    pre.A = 1.0;
+    pre.b = 0.0;
+    {
+      const int w = wave_id();
+      for (int i = 0; i < w; i++) {
+        Aff g;
+        g.A = sc_f64[2 * i];
+        g.b = sc_f64[2 * i + 1];
+        pre = aff_then(pre, g);
+      }
+      Aff prev;
+      prev.A = __shfl_up(inc.A, 1, WAVE);
+      prev.b = __shfl_up(inc.b, 1, WAVE);
+      if (lane_id() == 0) {
+        prev.A = 1.0;
+        prev.b = 0.0;
+      }
+      pre = aff_then(pre, prev);
+    }
+    const unsigned prevbit = (tid > 0) ? ((cm[tid - 1] >> 7) & 1u) : 0u;
+    const unsigned nextbit = (tid < SYNC_THREADS - 1) ? (cm[tid + 1] & 1u) : 0u;
+    const unsigned ext = (cmask << 1) | prevbit;           // bit j+1 = cand[j], bit 0 = cand[-1]
+    const unsigned startmask = cmask & ~ext & 0xFFu;       // cand[j] && !cand[j-1]
+    const unsigned extn = (cmask >> 1) | (nextbit << 7);   // bit j = cand[j+1]
+    const unsigned endmask = cmask & ~extn & 0xFFu;        // cand[j] && !cand[j+1]
+    const int packed = (__popc(startmask) << 16) | __popc(cmask);
+    int ptot;
+    const int pex = block_excl_scan_add<int>(packed, sc_i32, &ptot);
+    const int nstart_before = pex >> 16, ncand_before = pex & 0xFFFF;
+    const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
+    if (tid == 0) {
+      unsigned long long basev = 0, basep = 0;
+      if (ncand > 0) {
+        basev = atomicAdd(p.cand_count, (unsigned long long)ncand);
+        basep = atomicAdd(p.piece_count, (unsigned long long)npieces);
+      }
+      bc[0] = basev;
+      bc[1] = basep;
+      if (basev + (unsigned long long)ncand > p.cand_cap || basep + (unsigned long long)npieces > p.piece_cap)
+        atomicOr(p.overflow, 1u);
     }
     __syncthreads();
-
-    // ---- 9. slide the y and M histories ---------------------------------------------------------
-    if (tile + 1 < tile_own1) {
-      for (int off = 0; off < HY; off += T) {
-        c32 v[SYNC_V];
+    const unsigned long long basev = bc[0], basep = bc[1];
+    const bool fits = (basev + (unsigned long long)ncand <= p.cand_cap) &&
+                      (basep + (unsigned long long)npieces <= p.piece_cap);
+    if (fits && ncand > 0) {
+      double a_loc = pre.b;  // zero-init average just before this thread's first sample
+      int so = nstart_before, co = ncand_before;
 #pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
-          if (i < HY && i < off + T) v[r] = ys[sync_lp(i + T)];
+      for (int j = 0; j < SYNC_V; j++) {
+        const int i = SYNC_V * tid + j;
+        const uint64_t n = t0 + (uint64_t)i;
+        if ((startmask >> j) & 1u) {
+          SyncPiece* pc = p.pieces + basep + so;
+          pc->start = n;
+          pc->val_off = basev + (unsigned long long)co;
+          pc->bloc = a_loc;
+          so++;
         }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
-          if (i < HY && i < off + T) ys[sync_lp(i)] = v[r];
+        if ((cmask >> j) & 1u) {
+          p.cand_u[basev + co] = u[j];
+          p.cand_P[basev + co] = Pe[i - amin];
+          co++;
         }
-        __syncthreads();
-      }
-      for (int off = 0; off < HM; off += T) {
-        float v[SYNC_V];
-#pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
-          if (i < HM && i < off + T) v[r] = ms[sync_lp(i + T)];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
-          if (i < HM && i < off + T) ms[sync_lp(i)] = v[r];
-        }
-        __syncthreads();
+        if ((endmask >> j) & 1u) p.pieces[basep + so - 1].end = n;
+        if (j < nv) a_loc = (double)p.alpha * (double)u[j] + p.decay * a_loc;
       }
     }
+    if (tid == 0) {
+      p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
+      p.tile_first[tile] = basep;
+    }
+    __syncthreads();  // Pe / ue / me are scratch that the next iteration overwrites
   }
 }
 
