@@ -129,46 +129,82 @@ struct DemodParams {
   uint8_t* tap_demapped;   // optional [nsym]
 };
 
+// LDS of one frame's workgroup: fft (2 buffers; the first doubles as the shifted spectrum, the second as
+// the |Y[i]-Y[i+2]|^2 scratch of the preamble) | hinv[occ] | dfe[occ] | constellation | reduction scratch |
+// the bits of one OFDM symbol
+__host__ __device__ inline int demod_symbits_words(int nmap, int nbits) { return (nmap * nbits + 8 + 31) / 32 + 2; }
 template <int N>
-__host__ __device__ constexpr int demod_lds_bytes(int occ) {
-  // fft (2 buffers) | hinv[occ] | dfe[occ] | sd/red scratch [N floats + 64] | bits [1536 words] | misc
-  return fft_lds_bytes(N) + 2 * occ * (int)sizeof(c32) + (N + 64) * (int)sizeof(float) + 1536 * 4 + 256;
+__host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int nbits) {
+  return fft_lds_bytes(N) + 2 * occ * (int)sizeof(c32) + arity * (int)sizeof(c32) + 64 * (int)sizeof(float) +
+         demod_symbits_words(nmap, nbits) * 4 + 64;
 }
 
-// sum over the N/8 threads of the frame
+// sum over the N/8 threads of the frame (two values at once)
 template <int T>
-__device__ __forceinline__ float block_sum_f(float v, float* red) {
+__device__ __forceinline__ void block_sum2_f(float& a, float& b, float* red) {
   if (T >= WAVE) {
-    v = wave_sum(v);
-    if (lane_id() == 0) red[wave_id()] = v;
-    __syncthreads();
-    float s = 0.f;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (T > WAVE) {
+      if (lane_id() == 0) {
+        red[2 * wave_id()] = a;
+        red[2 * wave_id() + 1] = b;
+      }
+      __syncthreads();
+      float sa = 0.f, sb = 0.f;
 #pragma unroll
-    for (int i = 0; i < T / WAVE; i++) s += red[i];
-    __syncthreads();
-    return s;
+      for (int i = 0; i < T / WAVE; i++) {
+        sa += red[2 * i];
+        sb += red[2 * i + 1];
+      }
+      __syncthreads();
+      a = sa;
+      b = sb;
+    }
   } else {
-    red[threadIdx.x] = v;
+    red[2 * threadIdx.x] = a;
+    red[2 * threadIdx.x + 1] = b;
     __syncthreads();
-    float s = 0.f;
-    for (int i = 0; i < T; i++) s += red[i];
+    float sa = 0.f, sb = 0.f;
+    for (int i = 0; i < T; i++) {
+      sa += red[2 * i];
+      sb += red[2 * i + 1];
+    }
     __syncthreads();
-    return s;
+    a = sa;
+    b = sb;
   }
 }
 
+struct dc {  // float64 complex, for the NCO phasor recurrences
+  double re, im;
+};
+__device__ __forceinline__ dc dmul(dc a, dc b) {
+  dc r;
+  r.re = a.re * b.re - a.im * b.im;
+  r.im = a.re * b.im + a.im * b.re;
+  return r;
+}
+__device__ __noinline__ dc dexpj(double ph) {
+  ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
+  dc r;
+  sincos(ph, &r.im, &r.re);
+  return r;
+}
+
 template <int N>
-__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodParams q) {
+__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, 3) k_rx_demod(DemodParams q) {
   constexpr int T = N / 8;
   extern __shared__ __align__(16) unsigned char smem[];
   c32* fftbuf = reinterpret_cast<c32*>(smem);
   c32* Ysh = fftbuf;  // the first FFT buffer is free again after the last pass: shifted spectrum, linear
+  float* sd = reinterpret_cast<float*>(fftbuf + fft_lds_points(N));  // second FFT buffer, free between transforms
   c32* hinv = fftbuf + 2 * fft_lds_points(N);
   c32* dfe = hinv + q.occ;
-  float* sd = reinterpret_cast<float*>(dfe + q.occ);
-  float* red = sd + N;
-  uint32_t* bits32 = reinterpret_cast<uint32_t*>(red + 64);
-  int* misc = reinterpret_cast<int*>(bits32 + 1536);
+  c32* cst = dfe + q.occ;
+  float* red = reinterpret_cast<float*>(cst + q.arity);
+  uint32_t* sbits = reinterpret_cast<uint32_t*>(red + 64);
+  const int sbw = demod_symbits_words(q.nmap, q.nbits);
 
   const int t = threadIdx.x;
   const uint32_t f = blockIdx.x;
@@ -178,18 +214,21 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodPar
   int sstate = 0;  // 0 search, 1 have_sync, 2 have_header
   float pll_phase = 0.f, pll_freq = 0.f;
   uint32_t nbits_total = 0;  // bits demapped since enter_have_sync
+  uint32_t hdr = 0, hdr_bytes = 0;
   uint32_t packetlen = 0, header_ok = 0;
-  bool done = false;      // sink went back to search
+  bool done = false;  // sink went back to search
   uint32_t status = FR_INCOMPLETE;
   uint32_t end_frame = f;
   int coarse = 0;
   unsigned phase_count = 1;
+  uint8_t* rawslot = q.raw + (uint64_t)f * RAW_SLOT;
 
-  for (int i = t; i < 1536; i += T) bits32[i] = 0;
+  for (int i = t; i < sbw; i += T) sbits[i] = 0;
   for (int i = t; i < q.occ; i += T) {
     hinv[i] = mk(0.f, 0.f);
     dfe[i] = mk(1.f, 0.f);
   }
+  for (int i = t; i < q.arity; i += T) cst[i] = q.constellation[i];
   __syncthreads();
 
   uint32_t cf = f;  // frame whose symbols are being consumed
@@ -197,55 +236,86 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodPar
     const uint32_t j = q.j0 + cf;
     const uint64_t p = q.peaks[j];
     const uint32_t K = q.K[j];
-    const double Phi = q.Phi[j], st = q.step[j];
     const uint64_t symb = q.sym_base[j];
+    const uint64_t s00 = p - (uint64_t)N + 1;  // first sample of the preamble symbol
+
+    // ---- NCO phasors (gr_frequency_modulator_fc closed form, float64) ---------------------------------
+    // data symbols live in segment j:  phi[n] = Phi_j + st_j * (n - p + 1); for symbol k, sample t + m*T:
+    //   n - p + 1 = k*L - N + 2 + t + m*T   =>   exp(j phi) = A * RL^k * RT^m
+    const double st = q.step[j];
+    dc A = dexpj(q.Phi[j] + st * (double)(2 - N + t));
+    const dc RL = dexpj(st * (double)q.L);
+    const dc RT = dexpj(st * (double)T);
+    // the preamble symbol ends ON the flag: its samples before p belong to the previous segment(s)
+    const bool pre_simple = (j == 0) || (q.peaks[j - 1] <= s00);
+    dc Ap = {1.0, 0.0}, RTp = {1.0, 0.0};
+    const dc Rflag = dexpj(q.Phi[j] + st);  // the flagged sample itself already runs on the new frequency
+    if (pre_simple && j > 0) {
+      const double stq = q.step[j - 1];
+      Ap = dexpj(q.Phi[j - 1] + stq * (double)((int64_t)(s00 + (uint64_t)t) - (int64_t)q.peaks[j - 1] + 1));
+      RTp = dexpj(stq * (double)T);
+    }
+
+    // prefetch of the next symbol's samples
+    c32 nx[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) nx[m] = q.y[s00 + (uint64_t)(t + m * T)];
+
+    dc base = A;  // A * RL^k
     for (uint32_t k = 0; k <= K; k++) {
       if (done && !q.tap_mode) break;
-      const uint64_t s0 = p + (uint64_t)k * (uint64_t)q.L - (uint64_t)N + 1;
-      // ---- sigmix: chan_filt * exp(j phi[n]) ---------------------------------------------
+      // Opaque copy of the thread index: without it the compiler hoists every tid-dependent LDS / twiddle
+      // address of the three FFT passes out of the symbol loop and then spills them (170+ VGPRs).
+      int tl = t;
+      asm volatile("" : "+v"(tl));
       c32 e[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) e[m] = nx[m];
+      if (k < K) {
+        const uint64_t s1 = s00 + (uint64_t)(k + 1) * (uint64_t)q.L;
+#pragma unroll
+        for (int m = 0; m < 8; m++) nx[m] = q.y[s1 + (uint64_t)(t + m * T)];
+      }
+      // ---- sigmix: chan_filt * exp(j phi[n]) ---------------------------------------------
       if (k > 0) {
-        // all N samples lie after flag j and before flag j+1: one NCO segment, closed form
-        double ph0 = Phi + st * (double)((int64_t)(s0 + (uint64_t)t) - (int64_t)p + 1);
-        ph0 = ph0 - 6.283185307179586476925 * floor(ph0 / 6.283185307179586476925 + 0.5);
-        double bs, bc;
-        sincos(ph0, &bs, &bc);
-        double ws_, wc_;
-        sincos(st * (double)T, &ws_, &wc_);
-        double rc = 1.0, rs = 0.0;  // exp(j * st * m * T)
+        base = dmul(base, RL);
+        dc r = base;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-          const double cr = bc * rc - bs * rs, ci = bc * rs + bs * rc;
-          const c32 v = q.y[s0 + (uint64_t)(t + m * T)];
-          e[m] = cmul(v, mk((float)cr, (float)ci));
-          const double nrc = rc * wc_ - rs * ws_, nrs = rc * ws_ + rs * wc_;
-          rc = nrc;
-          rs = nrs;
+          e[m] = cmul(e[m], mk((float)r.re, (float)r.im));
+          r = dmul(r, RT);
+        }
+      } else if (pre_simple) {
+        dc r = Ap;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          c32 rot = mk((float)r.re, (float)r.im);
+          if (t + m * T == N - 1) rot = mk((float)Rflag.re, (float)Rflag.im);
+          e[m] = cmul(e[m], rot);
+          r = dmul(r, RTp);
         }
       } else {
-        // the preamble symbol ends ON the flag: its samples belong to earlier NCO segments
+        // two flags closer than one FFT length: look every sample's segment up
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-          const uint64_t n = s0 + (uint64_t)(t + m * T);
+          const uint64_t n = s00 + (uint64_t)(t + m * T);
           int64_t i = (int64_t)j;
           while (i >= 0 && q.peaks[i] > n) i--;
           double ph = 0.0;
           if (i >= 0) ph = q.Phi[i] + q.step[i] * (double)(n - q.peaks[i] + 1);
-          ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
-          double sn, cs;
-          sincos(ph, &sn, &cs);
-          e[m] = cmul(q.y[n], mk((float)cs, (float)sn));
+          const dc r = dexpj(ph);
+          e[m] = cmul(e[m], mk((float)r.re, (float)r.im));
         }
       }
       // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
-      fft_run<N, false>(e, t, fftbuf, q.tw, [] { __syncthreads(); });
-      __syncthreads();  // the last pass read buffer B/A: every thread done before Ysh (= A) is overwritten
+      fft_run<N, false>(e, tl, fftbuf, q.tw, [] { __syncthreads(); });
+      __syncthreads();  // every thread is done reading the FFT buffers before Ysh (= buffer A) is overwritten
 #pragma unroll
-      for (int m = 0; m < 8; m++) Ysh[(t + m * T + N / 2) & (N - 1)] = e[m];
+      for (int m = 0; m < 8; m++) Ysh[(tl + m * T + N / 2) & (N - 1)] = e[m];
       __syncthreads();
       if (q.tap_fft) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) q.tap_fft[(symb + k) * (uint64_t)N + (uint64_t)(t + m * T)] = Ysh[t + m * T];
+        for (int m = 0; m < 8; m++) q.tap_fft[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = Ysh[tl + m * T];
       }
 
       // ---- digital_ofdm_frame_acquisition ------------------------------------------------------
@@ -262,17 +332,22 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodPar
         __syncthreads();
         int index = 0;
         float mx = 0.f;
-        for (int i0 = q.zl - q.shift; i0 < q.zl + q.shift; i0++) {
-          float part = 0.f;
+        for (int i0 = q.zl - q.shift; i0 < q.zl + q.shift; i0 += 2) {
+          float pa = 0.f, pb = 0.f;
           for (int jj = t; jj < q.occ; jj += T) {
-            const int qi = i0 + jj;
-            const float s2 = (qi >= 0 && qi < N) ? sd[qi] : 0.f;
-            part = part + q.kd[jj] * s2;
+            const float kdv = q.kd[jj];
+            const int qa = i0 + jj, qb = i0 + 1 + jj;
+            pa = pa + kdv * ((qa >= 0 && qa < N) ? sd[qa] : 0.f);
+            pb = pb + kdv * ((qb >= 0 && qb < N) ? sd[qb] : 0.f);
           }
-          const float sum = block_sum_f<T>(part, red);
-          if (sum > mx) {
-            mx = sum;
+          block_sum2_f<T>(pa, pb, red);
+          if (pa > mx) {
+            mx = pa;
             index = i0;
+          }
+          if (i0 + 1 < q.zl + q.shift && pb > mx) {
+            mx = pb;
+            index = i0 + 1;
           }
         }
         coarse = index - q.zl;
@@ -323,7 +398,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodPar
       }
       // demapper
       const c32 carrier = mk(cosf(pll_phase), sinf(pll_phase));
-      c32 accp = mk(0.f, 0.f);
+      float are = 0.f, aim = 0.f;
+      const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
         const int i = q.smap[c];
         const int yi = i + q.zl + coarse;
@@ -332,18 +408,18 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodPar
         const c32 sigrot = cmul(cmul(in, carrier), dfe[c]);
         // slicer: first minimum of |x - pos[j]|^2
         unsigned best = 0;
-        float bestd = cnorm(csub(sigrot, q.constellation[0]));
+        float bestd = cnorm(csub(sigrot, cst[0]));
         for (int jj = 1; jj < q.arity; jj++) {
-          const float dd = cnorm(csub(sigrot, q.constellation[jj]));
+          const float dd = cnorm(csub(sigrot, cst[jj]));
           if (dd < bestd) {
             bestd = dd;
             best = (unsigned)jj;
           }
         }
-        const c32 closest = q.constellation[best];
+        const c32 closest = cst[best];
         const c32 er = cmul_conj(sigrot, closest);
-        accp.re = accp.re + er.re;
-        accp.im = accp.im + er.im;
+        are = are + er.re;
+        aim = aim + er.im;
         if (cnorm(sigrot) > 0.001f) {
           const c32 qq = cdiv(closest, sigrot);
           c32 d = dfe[c];
@@ -352,28 +428,31 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodPar
           dfe[c] = d;
         }
         if (q.tap_sink) q.tap_sink[(symb + k) * (uint64_t)q.occ + (uint64_t)c] = sigrot;
-        // LSB-first bit packing into the message buffer
-        const uint32_t bp = nbits_total + (uint32_t)c * (uint32_t)q.nbits;
-        if ((bp >> 5) < 1535u) {
-          atomicOr(&bits32[bp >> 5], best << (bp & 31));
-          if ((bp & 31) + (uint32_t)q.nbits > 32u) atomicOr(&bits32[(bp >> 5) + 1], best >> (32 - (bp & 31)));
-        }
+        // LSB-first bit packing into this symbol's bit buffer
+        const uint32_t bp = carry_bits + (uint32_t)c * (uint32_t)q.nbits;
+        atomicOr(&sbits[bp >> 5], best << (bp & 31));
+        if ((bp & 31) + (uint32_t)q.nbits > 32u) atomicOr(&sbits[(bp >> 5) + 1], best >> (32 - (bp & 31)));
       }
       if (q.tap_demapped && t == 0) q.tap_demapped[symb + k] = 1;
-      const float are = block_sum_f<T>(accp.re, red);
-      const float aim = block_sum_f<T>(accp.im, red);
+      block_sum2_f<T>(are, aim, red);
       const float angle = atan2f(aim, are);
       pll_freq = pll_freq - q.freq_gain * angle;
       pll_phase = pll_phase + pll_freq - q.phase_gain * angle;
       if (pll_phase >= 6.28318530717958647692f) pll_phase -= 6.28318530717958647692f;
       if (pll_phase < 0.0f) pll_phase += 6.28318530717958647692f;
+      __syncthreads();  // sbits complete for this symbol
+      // ---- bytes of this symbol: header parse, message bytes to the raw slot -----------------------
+      const uint32_t byte0 = nbits_total >> 3;                           // index of the byte at sbits bit 0
       nbits_total += (uint32_t)q.nmap * (uint32_t)q.nbits;
-      __syncthreads();  // bits32 complete for this symbol
-      const uint32_t nbytes = nbits_total >> 3;
-      if (sstate == 1 && nbytes >= 4) {
-        const uint32_t w = bits32[0];
-        // bytes arrive in order b0..b3; the header is assembled MSB first
-        const uint32_t hdr = ((w & 0xFF) << 24) | (((w >> 8) & 0xFF) << 16) | (((w >> 16) & 0xFF) << 8) | (w >> 24);
+      const uint32_t nbytes = nbits_total >> 3;                          // complete bytes so far
+      const uint32_t nnew = nbytes - byte0;                              // complete bytes in the buffer
+      const uint8_t* sb8 = reinterpret_cast<const uint8_t*>(sbits);
+      // header bytes (the first four of the frame) are assembled MSB first
+      for (uint32_t b = byte0; b < nbytes && b < 4; b++) {
+        hdr = (hdr << 8) | sb8[b - byte0];
+        hdr_bytes++;
+      }
+      if (sstate == 1 && hdr_bytes == 4) {
         if (((hdr >> 16) ^ (hdr & 0xFFFF)) == 0) {
           header_ok = 1;
           packetlen = (hdr >> 16) & 0x0FFF;
@@ -384,36 +463,40 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8) k_rx_demod(DemodPar
           end_frame = cf;
         }
       }
-      if (sstate == 2 && nbytes >= 4 + packetlen) {
-        status = FR_COMPLETE;
-        done = true;
-        end_frame = cf;
+      if (sstate == 2) {
+        // message byte i (i >= 0) is frame byte 4+i
+        const uint32_t lim = 4 + packetlen;
+        for (uint32_t b = byte0 + t; b < nbytes; b += T)
+          if (b >= 4 && b < lim) rawslot[b - 4] = sb8[b - byte0];
+        if (nbytes >= lim) {
+          status = FR_COMPLETE;
+          done = true;
+          end_frame = cf;
+        }
+      }
+      __syncthreads();
+      // carry the unfinished byte into the next symbol's buffer, clear the rest
+      {
+        const uint32_t keep = (nbits_total & 7u) ? sb8[nnew] : 0u;
+        __syncthreads();
+        for (int i = t; i < sbw; i += T) sbits[i] = (i == 0) ? keep : 0u;
+        __syncthreads();
       }
     }
-    if (done && !q.tap_mode) break;
-    if (done && q.tap_mode) break;  // remaining symbols of frame cf were tapped in the loop above
+    if (done) break;
     if (cf + 1 >= q.nframes) break;
     cf++;  // the next preamble arrives while the sink is not searching: it is consumed as data
   }
   if (!done) end_frame = q.nframes - 1;
 
-  if (!q.tap_mode) {
-    // message bytes (after the 4 header bytes) -> raw slot, word-wise
-    if (status == FR_COMPLETE) {
-      uint32_t* dst = reinterpret_cast<uint32_t*>(q.raw + (uint64_t)f * RAW_SLOT);
-      const uint32_t nw = (packetlen + 3) >> 2;
-      for (uint32_t i = t; i < nw; i += T) dst[i] = bits32[1 + i];
-    }
-    if (t == 0) {
-      FrameResult r;
-      r.status = status;
-      r.packetlen = packetlen;
-      r.end_frame = end_frame;
-      r.header_ok = header_ok;
-      q.res[f] = r;
-    }
+  if (!q.tap_mode && t == 0) {
+    FrameResult r;
+    r.status = status;
+    r.packetlen = packetlen;
+    r.end_frame = end_frame;
+    r.header_ok = header_ok;
+    q.res[f] = r;
   }
-  (void)misc;
 }
 
 // ------------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ struct SyncParams {
   int ntaps_pad;  // multiple of 8
   int tiles_per_seg, nwarm;
   int exact_all;  // metric tap: evaluate every sample in fixed point
+  int ablate;     // timing experiments only (OFDM_ABLATE): 1 skip filter taps, 2 skip metric, 4 skip y store
   uint64_t nsamples, ntiles;
   float tapcp;       // float(1/CP)
   float cand_thr;    // -max(rise, fall)
@@ -412,7 +413,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       // compiler (static indices, no moves); it is re-read from LDS at the top of every iteration so
       // that nothing but one index is carried around the loop.  The taps of an iteration sit in SGPRs.
       int gw = gb;
-      for (int kb = 0; kb < p.ntaps_pad; kb += 8 * U) {
+      for (int kb = 0; kb < ((p.ablate & 1) ? 8 * U : p.ntaps_pad); kb += 8 * U) {
         c32 w[15];  // w[d] = x[out0 - kb - 7 + d]
 #pragma unroll
         for (int d = 0; d < 7; d++) w[d] = xs[gw + 1 + d];
@@ -449,7 +450,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     for (int i = tid; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
 
     // ---- 3. y to HBM (owned tiles only), coalesced from LDS ----------------------------
-    if (owned) {
+    if (owned && !(p.ablate & 4)) {
       if (y_al16 && t0 + (uint64_t)T <= p.nsamples) {
         float4* dst = reinterpret_cast<float4*>(p.y + t0);
 #pragma unroll
@@ -469,6 +470,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       }
     }
 
+    if (p.ablate & 2) {
+      __syncthreads();
+      continue;
+    }
     // ---- 4. float32 Schmidl-Cox sums, anchored at the tile start --------------------------
     float pfr[SYNC_V], pfi[SYNC_V], pfe[SYNC_V];
     F3 tsum = {0.f, 0.f, 0.f};
