@@ -147,19 +147,17 @@ __host__ __device__ __forceinline__ uint32_t pad_symbol_hash(uint64_t seed, uint
   return (uint32_t)((z >> 32) % arity);
 }
 
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+// Philox-2x32-10 (Salmon et al., SC'11): counter = sample index, key = stream key
+__host__ __device__ __forceinline__ uint32_t chan_key(uint64_t seed, uint64_t stream) {
+  return (uint32_t)seed ^ (uint32_t)(seed >> 32) ^ ((uint32_t)stream * 0x9E3779B9u + (uint32_t)(stream >> 32) * 0x85EBCA6Bu);
+}
+__device__ __forceinline__ void philox2x32_10(uint32_t& c0, uint32_t& c1, uint32_t k) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    uint32_t n0 = hi1 ^ c[1] ^ k0;
-    uint32_t n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0;
-    c[1] = lo1;
-    c[2] = n2;
-    c[3] = lo0;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
+    const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
+    c0 = hi ^ k ^ c1;
+    c1 = lo;
+    k += 0x9E3779B9u;
   }
 }
 
@@ -174,16 +172,17 @@ __device__ __forceinline__ c32 channel_apply(c32 x, uint64_t idx, float sigma, f
     x = cmul(x, mk((float)c, (float)s));
   }
   if (sigma > 0.0f) {
-    uint32_t ctr[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
-    philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32);
+    philox2x32_10(c0, c1, chan_key(seed, stream));
     const float inv24 = 1.0f / 16777216.0f;
-    float u1 = ((float)(ctr[0] >> 8) + 0.5f) * inv24;
-    float u2 = ((float)(ctr[1] >> 8) + 0.5f) * inv24;
-    float rad = sqrtf(-2.0f * logf(u1));
-    float th = 6.28318530717958647692f * u2;
-    float sn, cs;
-    sincosf(th, &sn, &cs);
-    float s = sigma * 0.70710678118654752440f;
+    const float u1 = ((float)(c0 >> 8) + 0.5f) * inv24;
+    const float u2 = ((float)(c1 >> 8) + 0.5f) * inv24;
+    // Box-Muller on the hardware transcendental units: v_log_f32 (log2) and v_sin/v_cos_f32, whose
+    // argument is in revolutions -- exactly u2.  A few 1e-7 off libm, scaled by sigma: far below the
+    // float32 resolution of the signal it is added to.
+    const float rad = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln(u1) = -2 ln2 log2(u1)
+    const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
+    const float s = sigma * 0.70710678118654752440f;
     x.re = x.re + s * (rad * cs);
     x.im = x.im + s * (rad * sn);
   }

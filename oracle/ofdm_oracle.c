@@ -461,27 +461,21 @@ int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload
 /* ------------------------------------------------------------------------ */
 /* synthetic channel (stands in for the UHD sink/source pair)                */
 /* ------------------------------------------------------------------------ */
-static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-  for (int r = 0; r < 10; r++) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    uint32_t n3 = (uint32_t)p0;
-    c[0] = n0;
-    c[1] = n1;
-    c[2] = n2;
-    c[3] = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
+/* Philox-2x32-10 (Salmon et al., SC'11): counter = sample index, key = stream key */
+static inline uint32_t chan_key(uint64_t seed, uint64_t stream) {
+  return (uint32_t)seed ^ (uint32_t)(seed >> 32) ^ ((uint32_t)stream * 0x9E3779B9u + (uint32_t)(stream >> 32) * 0x85EBCA6Bu);
 }
-
-void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[4]) {
-  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  memcpy(out, c, sizeof(c));
+void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[2]) {
+  uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), k = chan_key(seed, stream);
+  for (int r = 0; r < 10; r++) {
+    uint64_t p = (uint64_t)0xD256D193u * c0;
+    uint32_t hi = (uint32_t)(p >> 32), lo = (uint32_t)p;
+    c0 = hi ^ k ^ c1;
+    c1 = lo;
+    k += 0x9E3779B9u;
+  }
+  out[0] = c0;
+  out[1] = c1;
 }
 
 int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0) {
@@ -496,7 +490,7 @@ int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0) 
       x = cmul(x, r);
     }
     if (ch->sigma > 0.0f) {
-      uint32_t r[4];
+      uint32_t r[2];
       orc_philox(ch->seed, ch->stream_id, idx, r);
       float u1 = ((float)(r[0] >> 8) + 0.5f) * inv24;
       float u2 = ((float)(r[1] >> 8) + 0.5f) * inv24;
