@@ -92,7 +92,9 @@ EXPORTS = (
 )
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libofdm_hip.so")
+# OFDM_HIP_LIB selects another build of the same library (e.g. the -DSYNC_STAMPS diagnostic build)
+LIB_PATH = os.environ.get("OFDM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc",
+                                                         "libofdm_hip.so")
 
 
 def _declare(lib):

@@ -43,7 +43,7 @@ struct ofdm_handle {
   std::string err;
 
   // constant tables
-  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_taps, d_ks, d_smap, d_kd;
+  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_taps, d_ks, d_smap, d_kd, d_xp8;
 
   // TX workspaces
   DevBuf d_payloads, d_payload_off, d_payload_len, d_framed, d_framed_off, d_sym_off, d_sym_pkt, d_iq_stage,
@@ -249,6 +249,17 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   HIPCHK(h, upload(h->d_bin2car, bin2car.data(), bin2car.size()));
   HIPCHK(h, upload(h->d_mask, cfg->whitening_mask, (size_t)OFDM_MASK_LEN));
   HIPCHK(h, upload(h->d_crc, crc, (size_t)256));
+  {
+    // x^(8k) mod P for k = 0..4096 in zlib's reflected representation (x^0 = 0x80000000): the operator
+    // of crc32_combine for k following bytes
+    std::vector<uint32_t> xp8(OFDM_MASK_LEN + 1);
+    uint32_t v = 0x80000000u;
+    for (size_t k = 0; k < xp8.size(); k++) {
+      xp8[k] = v;
+      for (int b = 0; b < 8; b++) v = (v & 1u) ? ((v >> 1) ^ 0xEDB88320u) : (v >> 1);  // times x
+    }
+    HIPCHK(h, upload(h->d_xp8, xp8.data(), xp8.size()));
+  }
   HIPCHK(h, upload(h->d_taps, taps.data(), taps.size()));
   HIPCHK(h, upload(h->d_ks, reinterpret_cast<const c32*>(cfg->known_symbol), (size_t)occ));
   HIPCHK(h, upload(h->d_smap, smap16.data(), smap16.size()));
@@ -284,7 +295,7 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
   if (!h) return;
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   DevBuf* bufs[] = {&h->d_const,    &h->d_preamble,    &h->d_tw,          &h->d_bin2car, &h->d_mask,
-                    &h->d_crc,      &h->d_taps,        &h->d_ks,          &h->d_smap,    &h->d_kd,
+                    &h->d_crc,      &h->d_taps,        &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
                     &h->d_payloads, &h->d_payload_off, &h->d_payload_len, &h->d_framed,  &h->d_framed_off,
                     &h->d_sym_off,  &h->d_sym_pkt,     &h->d_iq_stage,    &h->d_freq_tap};
   for (DevBuf* b : bufs) b->release();

@@ -551,6 +551,7 @@ struct DeframeParams {
   const uint8_t* raw;
   const uint8_t* mask;
   const uint32_t* crc_table;
+  const uint32_t* xp8;  // [4097] x^(8k) mod P, reflected (crc32_combine operator for k following bytes)
   uint64_t* key;        // [nframes] (is_message << 40) | payload_bytes
   const uint64_t* pos;  // exclusive scan of key
   uint8_t* payload_out;
@@ -580,11 +581,28 @@ __global__ void __launch_bounds__(256) k_deframe_count(DeframeParams q) {
   q.key[f] = key;
 }
 
+// a(x) * b(x) mod P(x) in the reflected representation zlib uses for crc32_combine (x^0 = bit 31)
+__device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    p ^= (0u - ((a >> (31 - i)) & 1u)) & b;
+    b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+  }
+  return p;
+}
+
+// One WAVE per frame: coalesced 16-byte loads of the raw message, dewhitening, CRC-32 as 64 independent
+// 16-byte CRCs per KiB combined with crc(A||B) = crc(A) * x^(8|B|) + crc(B)  (mod P), and dword-aligned
+// coalesced stores of the payload through an LDS staging line.
 __global__ void __launch_bounds__(256) k_deframe_write(DeframeParams q) {
   __shared__ uint32_t tab[256];
+  __shared__ __align__(16) uint32_t stage_all[4][260];
   tab[threadIdx.x] = q.crc_table[threadIdx.x];
   __syncthreads();
-  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = lane_id(), w = wave_id();
+  uint32_t* stage = stage_all[w];
+  const uint32_t f = blockIdx.x * 4 + (uint32_t)w;
   if (f >= q.nframes) return;
   if (q.invalid[f]) return;
   const FrameResult r = q.res[f];
@@ -594,30 +612,68 @@ __global__ void __launch_bounds__(256) k_deframe_write(DeframeParams q) {
   const uint32_t len = r.packetlen;
   const uint32_t plen = len >= 4 ? len - 4 : 0;
   if (ord >= q.max_pkts || boff + plen > q.payload_cap) {
-    atomicAdd((unsigned long long*)&q.counters[4], 1ull);
+    if (lane == 0) atomicAdd((unsigned long long*)&q.counters[4], 1ull);
     return;
   }
   const uint8_t* msg = q.raw + (uint64_t)f * RAW_SLOT;
+  const uint4* msg4 = reinterpret_cast<const uint4*>(msg);
+  const uint4* mask4 = reinterpret_cast<const uint4*>(q.mask);
   uint8_t* out = q.payload_out + boff;
+  uint32_t acc = 0;
   // dewhiten with offset 0 (ofdm.py:303 passes no offset) and check the CRC (crc.check_crc32)
-  int ok = 0;
-  if (len >= 4) {
-    uint32_t crc = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < plen; i++) {
-      const uint8_t b = msg[i] ^ q.mask[i];
-      crc = tab[(crc ^ b) & 0xFF] ^ (crc >> 8);
-      out[i] = b;
+  for (uint32_t c0 = 0; c0 < plen; c0 += 1024) {
+    const uint32_t o = c0 + 16u * (uint32_t)lane;
+    uint4 d = make_uint4(0, 0, 0, 0);
+    if (o < plen) {
+      const uint4 m = msg4[o >> 4], k = mask4[o >> 4];
+      d = make_uint4(m.x ^ k.x, m.y ^ k.y, m.z ^ k.z, m.w ^ k.w);
+      const uint32_t nb = (plen - o < 16u) ? (plen - o) : 16u;
+      uint32_t crc = 0xFFFFFFFFu;
+      const uint32_t wds[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int b = 0; b < 16; b++) {
+        if ((uint32_t)b < nb) {
+          const uint32_t byte = (wds[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+          crc = tab[(crc ^ byte) & 0xFF] ^ (crc >> 8);
+        }
+      }
+      crc ^= 0xFFFFFFFFu;
+      acc ^= crc_multmodp(q.xp8[plen - (o + nb)], crc);
     }
-    crc ^= 0xFFFFFFFFu;
-    const uint32_t got = ((uint32_t)(msg[plen] ^ q.mask[plen]) << 24) | ((uint32_t)(msg[plen + 1] ^ q.mask[plen + 1]) << 16) |
-                         ((uint32_t)(msg[plen + 2] ^ q.mask[plen + 2]) << 8) | (uint32_t)(msg[plen + 3] ^ q.mask[plen + 3]);
-    ok = (crc == got);
+    // ---- payload bytes of this KiB to the output, dword-aligned ------------------------------
+    reinterpret_cast<uint4*>(stage)[lane] = d;
+    if (lane == 0) stage[256] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the staging line is written
+    const uint32_t rem = (plen - c0 < 1024u) ? (plen - c0) : 1024u;
+    uint8_t* og = out + c0;
+    const uint32_t head0 = (4u - (uint32_t)((uintptr_t)og & 3u)) & 3u;
+    const uint32_t head = head0 < rem ? head0 : rem;
+    const uint32_t nd = (rem - head) >> 2;
+    const uint8_t* st8 = reinterpret_cast<const uint8_t*>(stage);
+    if ((uint32_t)lane < head) og[lane] = st8[lane];
+    for (uint32_t dw = (uint32_t)lane; dw < nd; dw += WAVE) {
+      const uint32_t i0 = head + 4u * dw;
+      const uint32_t w0 = stage[i0 >> 2], w1 = stage[(i0 >> 2) + 1];
+      reinterpret_cast<uint32_t*>(og + i0)[0] = __builtin_amdgcn_alignbyte(w1, w0, i0 & 3u);
+    }
+    const uint32_t tail0 = head + 4u * nd;
+    if (tail0 + (uint32_t)lane < rem) og[tail0 + lane] = st8[tail0 + lane];
+    __builtin_amdgcn_wave_barrier();
   }
-  q.out_off[ord] = boff;
-  q.out_len[ord] = plen;
-  q.out_ok[ord] = (uint8_t)ok;
-  atomicAdd((unsigned long long*)&q.counters[1], 1ull);
-  if (ok) atomicAdd((unsigned long long*)&q.counters[2], 1ull);
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, WAVE);
+  if (lane == 0) {
+    int ok = 0;
+    if (len >= 4) {
+      const uint32_t got = ((uint32_t)(msg[plen] ^ q.mask[plen]) << 24) | ((uint32_t)(msg[plen + 1] ^ q.mask[plen + 1]) << 16) |
+                           ((uint32_t)(msg[plen + 2] ^ q.mask[plen + 2]) << 8) | (uint32_t)(msg[plen + 3] ^ q.mask[plen + 3]);
+      ok = (acc == got);  // crc32 of an empty payload is 0 = the empty XOR
+    }
+    q.out_off[ord] = boff;
+    q.out_len[ord] = plen;
+    q.out_ok[ord] = (uint8_t)ok;  // (packet / CRC totals are summed by the host from these flags)
+  }
 }
 
 // raw (pre-dewhitening) messages, concatenated in stream order, for the PACKETS tap

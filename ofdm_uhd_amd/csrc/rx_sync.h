@@ -32,6 +32,8 @@
 #define SYNC_TILE (SYNC_THREADS * SYNC_V)   // 2048 samples per tile
 #define SYNC_GUARD 1.0e-3f                  // guard band of the float32 pre-selection
 #define SYNC_MAX_TAPS OFDM_MAX_TAPS
+#define SYNC_CHUNK_C 4096                   // candidates per allocation chunk (>= SYNC_TILE)
+#define SYNC_CHUNK_P 1024                   // pieces per allocation chunk (>= SYNC_TILE / 2)
 
 struct SyncPiece {
   uint64_t start;    // absolute sample index of the first candidate of the piece
@@ -49,6 +51,7 @@ struct SyncParams {
   int tiles_per_seg, nwarm;
   int exact_all;  // metric tap: evaluate every sample in fixed point
   int ablate;     // timing experiments only (OFDM_ABLATE): 1 skip filter taps, 2 skip metric, 4 skip y store
+  unsigned long long* stamps;  // diagnostic build (-DSYNC_STAMPS): [wg][8] cycles per phase of wave 0
   uint64_t nsamples, ntiles;
   float tapcp;       // float(1/CP)
   float cand_thr;    // -max(rise, fall)
@@ -61,6 +64,8 @@ struct SyncParams {
   double* tile_B;          // [ntiles] zero-init running average over the tile
   uint32_t* tile_npieces;  // [ntiles] candidate pieces of the tile ...
   uint64_t* tile_first;    // [ntiles] ... stored at pieces[tile_first .. +tile_npieces)
+  // candidate / piece storage is handed out in chunks (one atomic per SYNC_CHUNK_C candidates instead of
+  // one per tile: no round-trip latency on the common path)
   SyncPiece* pieces;       // [piece_cap]
   uint64_t piece_cap;
   unsigned long long* piece_count;  // device counter
@@ -188,6 +193,54 @@ struct Q3 {
   long long pr, pi, r;
 };
 
+// exclusive block scan of three int64 plus block sum of three more: one barrier pair.
+// scratch: 4 waves x 6 int64 (rare path: plain shuffles)
+__device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scratch, Q3* excl, Q3* sum) {
+  const int lane = lane_id(), w = wave_id();
+  Q3 inc = v, rs = s;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const long long a = __shfl_up(inc.pr, d, WAVE), b = __shfl_up(inc.pi, d, WAVE), c = __shfl_up(inc.r, d, WAVE);
+    if (lane >= d) {
+      inc.pr += a;
+      inc.pi += b;
+      inc.r += c;
+    }
+  }
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    rs.pr += __shfl_xor(rs.pr, d, WAVE);
+    rs.pi += __shfl_xor(rs.pi, d, WAVE);
+    rs.r += __shfl_xor(rs.r, d, WAVE);
+  }
+  if (lane == WAVE - 1) {
+    scratch[w * 6 + 0] = inc.pr;
+    scratch[w * 6 + 1] = inc.pi;
+    scratch[w * 6 + 2] = inc.r;
+    scratch[w * 6 + 3] = rs.pr;
+    scratch[w * 6 + 4] = rs.pi;
+    scratch[w * 6 + 5] = rs.r;
+  }
+  __syncthreads();
+  Q3 base = {0, 0, 0}, sm = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
+    if (i < w) {
+      base.pr += scratch[i * 6 + 0];
+      base.pi += scratch[i * 6 + 1];
+      base.r += scratch[i * 6 + 2];
+    }
+    sm.pr += scratch[i * 6 + 3];
+    sm.pi += scratch[i * 6 + 4];
+    sm.r += scratch[i * 6 + 5];
+  }
+  __syncthreads();
+  excl->pr = base.pr + inc.pr - v.pr;
+  excl->pi = base.pi + inc.pi - v.pi;
+  excl->r = base.r + inc.r - v.r;
+  *sum = sm;
+}
+
 // ---------------------------------------------------------------------------------
 // Normative (Q23.40) evaluation of u = Mbar - 1 for the tile-relative samples [amin, bmax]:
 //   me[k]  exact M of sample amin-CP+1+k        (k < bmax-amin+CP)
@@ -235,13 +288,9 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
     tq.pi += a.pi - b.pi;
     tq.r += a.r - b.r;
   }
-  long long tot_, anpr, anpi, anr;
-  (void)block_excl_scan_add<long long>(an.pr, sc_i64, &anpr);
-  (void)block_excl_scan_add<long long>(an.pi, sc_i64 + 5, &anpi);
-  (void)block_excl_scan_add<long long>(an.r, sc_i64 + 10, &anr);
-  long long wpr = anpr + block_excl_scan_add<long long>(tq.pr, sc_i64, &tot_);
-  long long wpi = anpi + block_excl_scan_add<long long>(tq.pi, sc_i64 + 5, &tot_);
-  long long wr = anr + block_excl_scan_add<long long>(tq.r, sc_i64 + 10, &tot_);
+  Q3 ex, ansum;
+  block_scan3_sum3_i64(tq, an, sc_i64, &ex, &ansum);
+  long long wpr = ansum.pr + ex.pr, wpi = ansum.pi + ex.pi, wr = ansum.r + ex.r;
   for (int k = k0; k < k1; k++) {
     const int m = s0 + 1 + k;
     const Q3 a = QTERM(m), b = QTERM(m - D);
@@ -268,9 +317,9 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
   long long tm = 0;
   for (int jj = j0; jj < j1; jj++)
     if (jj > 0) tm += q40_from_float(me[CP - 1 + jj]) - q40_from_float(me[jj - 1]);
-  long long amt;
-  (void)block_excl_scan_add<long long>(am, sc_i64, &amt);
-  long long wm = amt + block_excl_scan_add<long long>(tm, sc_i64 + 5, &tot_);
+  Q3 mv = {tm, 0, 0}, ms_ = {am, 0, 0}, mex, msum;
+  block_scan3_sum3_i64(mv, ms_, sc_i64, &mex, &msum);
+  long long wm = msum.pr + mex.pr;
   for (int jj = j0; jj < j1; jj++) {
     if (jj > 0) wm += q40_from_float(me[CP - 1 + jj]) - q40_from_float(me[jj - 1]);
     const float mbar = (float)(q40_to_double(wm) * (double)tapcp);
@@ -280,8 +329,24 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 #undef QTERM
 }
 
+#ifdef SYNC_STAMPS
+#define STAMP(i)                                                             \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                      \
+    st_acc[i] += now_ - st_last;                                             \
+    st_last = now_;                                                          \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <int U>
 __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
+#ifdef SYNC_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   constexpr int T = SYNC_TILE;
@@ -292,11 +357,11 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   float* me = reinterpret_cast<float*>(smem + L.me);
   float* ue = reinterpret_cast<float*>(smem + L.ue);
   unsigned char* misc = smem + L.misc;
-  long long* sc_i64 = reinterpret_cast<long long*>(misc);      // 3 * 5 entries
-  double* sc_f64 = reinterpret_cast<double*>(misc + 128);      // 2 * 5 entries
-  int* sc_i32 = reinterpret_cast<int*>(misc + 256);            // 5 entries
+  long long* sc_i64 = reinterpret_cast<long long*>(misc);      // 24 entries
+  double* sc_f64 = reinterpret_cast<double*>(misc + 192);      // 2 * 5 entries
+  int* sc_i32 = reinterpret_cast<int*>(misc + 272);            // 5 entries
   unsigned char* cm = misc + 320;                               // 256 candidate masks
-  unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 576);  // 2 broadcast words
+  unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 576);  // 2 broadcast words (chunk allocation)
   float* scA = reinterpret_cast<float*>(misc + 608);           // 24 floats
   float* scB = reinterpret_cast<float*>(misc + 704);           // 8 floats
   float* scC = reinterpret_cast<float*>(misc + 736);           // 4 floats
@@ -334,6 +399,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   const int yb = sync_lp(HY + SYNC_V * tid), yb1 = sync_lp(HY - D + SYNC_V * tid), yb2 = sync_lp(HY - 2 * D + SYNC_V * tid);
   float4 xpre[SYNC_V / 2];
   bool have_pre = false;
+  // current allocation chunks of this workgroup (uniform across the block)
+  unsigned long long cand_base = 0, piece_base = 0;
+  uint32_t cand_left = 0, piece_left = 0;
   __syncthreads();
 
   for (uint64_t tile = tile_first; tile < tile_own1; tile++) {
@@ -394,6 +462,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     }
     for (int i = tid; i < HM; i += SYNC_THREADS) ms[sync_lp(i)] = ms[sync_lp(i + T)];  // HM <= T (checked by the host)
     __syncthreads();  // B1
+    STAMP(0);
 
     // prefetch the next tile of x; its latency hides behind the filter
     have_pre = false;
@@ -445,7 +514,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) ys[yb + j] = acc[j];
     }
+    STAMP(1);
     __syncthreads();  // B2
+    STAMP(2);
     // x history for the next tile: [T, T+HX) -> [0, HX) (disjoint, T >= HX); the rest of xs is scratch from here on
     for (int i = tid; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
 
@@ -534,8 +605,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         }
       }
     }
+    STAMP(3);
     F3 ex3, anch;
     block_scan3_sum3(tsum, anc, scA, &ex3, &anch);  // B3
+    STAMP(4);
     float Mv[SYNC_V];
     const int mb = sync_lp(HM + SYNC_V * tid);
 #pragma unroll
@@ -552,6 +625,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       ms[mb + j] = m;
     }
     __syncthreads();  // B4
+    STAMP(5);
 
     // ---- 5. CP-length moving average of M (float32), minus one -----------------------------
     float pm[SYNC_V];
@@ -565,6 +639,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     for (int m = -CP + tid; m < 0; m += SYNC_THREADS) manc += ms[sync_lp(HM + m)];
     float mex, mach;
     block_scan1_sum1(msum, manc, scB, &mex, &mach);  // B5
+    STAMP(6);
     if (!owned) continue;  // warm-up tile: only the histories matter
 
     float u[SYNC_V];
@@ -596,6 +671,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       if (lane_id() == WAVE - 1) scC[wave_id()] = bw;
     }
     const int anyc = __syncthreads_or(amask != 0);  // B6
+    STAMP(7);
     if (tid == 0) {
       p.tile_B[tile] = (double)((scC[0] + scC[1]) + (scC[2] + scC[3]));
       if (!anyc) p.tile_npieces[tile] = 0;
@@ -688,21 +764,22 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     const int pex = block_excl_scan_add<int>(packed, sc_i32, &ptot);
     const int nstart_before = pex >> 16, ncand_before = pex & 0xFFFF;
     const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
-    if (tid == 0) {
-      unsigned long long basev = 0, basep = 0;
-      if (ncand > 0) {
-        basev = atomicAdd(p.cand_count, (unsigned long long)ncand);
-        basep = atomicAdd(p.piece_count, (unsigned long long)npieces);
+    if ((uint32_t)ncand > cand_left || (uint32_t)npieces > piece_left) {
+      // rare: take fresh chunks (what is left of the old ones is simply not used)
+      if (tid == 0) {
+        bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);
+        bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);
       }
-      bc[0] = basev;
-      bc[1] = basep;
-      if (basev + (unsigned long long)ncand > p.cand_cap || basep + (unsigned long long)npieces > p.piece_cap)
-        atomicOr(p.overflow, 1u);
+      __syncthreads();
+      cand_base = bc[0];
+      piece_base = bc[1];
+      cand_left = SYNC_CHUNK_C;
+      piece_left = SYNC_CHUNK_P;
     }
-    __syncthreads();
-    const unsigned long long basev = bc[0], basep = bc[1];
-    const bool fits = (basev + (unsigned long long)ncand <= p.cand_cap) &&
-                      (basep + (unsigned long long)npieces <= p.piece_cap);
+    const unsigned long long basev = cand_base, basep = piece_base;
+    const bool fits = (basev + SYNC_CHUNK_C <= p.cand_cap + cand_left) && (basep + SYNC_CHUNK_P <= p.piece_cap + piece_left) &&
+                      (basev + (unsigned long long)ncand <= p.cand_cap) && (basep + (unsigned long long)npieces <= p.piece_cap);
+    if (!fits && tid == 0) atomicOr(p.overflow, 1u);
     if (fits && ncand > 0) {
       double a_loc = pre.b;  // zero-init average just before this thread's first sample
       int so = nstart_before, co = ncand_before;
@@ -730,8 +807,18 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
       p.tile_first[tile] = basep;
     }
+    if (fits) {
+      cand_base += (unsigned long long)ncand;
+      piece_base += (unsigned long long)npieces;
+      cand_left -= (uint32_t)ncand;
+      piece_left -= (uint32_t)npieces;
+    }
     __syncthreads();  // Pe / ue / me are scratch that the next iteration overwrites
   }
+#ifdef SYNC_STAMPS
+  if (p.stamps && threadIdx.x == 0)
+    for (int i = 0; i < 8; i++) p.stamps[blockIdx.x * 8 + i] = st_acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -793,40 +880,49 @@ __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
     int state = 0;
     float peak_val = -INFINITY;
     uint64_t peak_ind = 0;
-    c32 peak_P = mk(0.f, 0.f);
+    uint64_t peak_off = 0;  // where the peak's P sits in the candidate arrays (read only when a flag is raised)
     bool open_at_stream_end = false;
     for (;;) {
       const uint64_t len = pc.end - pc.start + 1;
-      for (uint64_t k = 0; k < len; k++) {
-        const float u = p.cand_u[pc.val_off + k];
-        const uint64_t i = pc.start + k;
-        for (;;) {
-          if (state == 0) {
-            if (u > avg * p.rise) {
-              state = 1;
-              continue;
+      for (uint64_t kb = 0; kb < len; kb += 8) {
+        // eight values per trip: the loads are independent of the state machine, so issue them together
+        float ub[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) ub[e] = (kb + e < len) ? p.cand_u[pc.val_off + kb + e] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const uint64_t k = kb + e;
+          if (k >= len) break;
+          const float u = ub[e];
+          const uint64_t i = pc.start + k;
+          for (;;) {
+            if (state == 0) {
+              if (u > avg * p.rise) {
+                state = 1;
+                continue;
+              }
+              avg = p.alpha * u + one_m_alpha * avg;
+              break;
             }
-            avg = p.alpha * u + one_m_alpha * avg;
-            break;
+            if (u > peak_val) {
+              peak_val = u;
+              peak_ind = i;
+              peak_off = pc.val_off + k;
+              avg = p.alpha * u + one_m_alpha * avg;
+              break;
+            }
+            if (u > avg * p.fall) {
+              avg = p.alpha * u + one_m_alpha * avg;
+              break;
+            }
+            if (WRITE) {
+              p.peaks[wbase + nflag] = peak_ind;
+              p.peak_P[wbase + nflag] = p.cand_P[peak_off];
+            }
+            nflag++;
+            state = 0;
+            peak_val = -INFINITY;
           }
-          if (u > peak_val) {
-            peak_val = u;
-            peak_ind = i;
-            peak_P = p.cand_P[pc.val_off + k];
-            avg = p.alpha * u + one_m_alpha * avg;
-            break;
-          }
-          if (u > avg * p.fall) {
-            avg = p.alpha * u + one_m_alpha * avg;
-            break;
-          }
-          if (WRITE) {
-            p.peaks[wbase + nflag] = peak_ind;
-            p.peak_P[wbase + nflag] = peak_P;
-          }
-          nflag++;
-          state = 0;
-          peak_val = -INFINITY;
         }
       }
       // does the interval continue in the next tile?
@@ -846,7 +942,7 @@ __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
     if (state == 1 && !open_at_stream_end) {
       if (WRITE) {
         p.peaks[wbase + nflag] = peak_ind;
-        p.peak_P[wbase + nflag] = peak_P;
+        p.peak_P[wbase + nflag] = p.cand_P[peak_off];
       }
       nflag++;
     }
