@@ -344,7 +344,7 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 template <int U>
 __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
   extern __shared__ __align__(16) unsigned char smem[];
@@ -630,10 +630,19 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     // ---- 5. CP-length moving average of M (float32), minus one -----------------------------
     float pm[SYNC_V];
     float msum = 0.f;
+    if ((CP & 7) == 0) {  // (HM - CP) is a multiple of 8: one base index, constant offsets
+      const int mo = sync_lp(HM - CP + SYNC_V * tid);
 #pragma unroll
-    for (int j = 0; j < SYNC_V; j++) {
-      msum += Mv[j] - ms[sync_lp(HM + SYNC_V * tid + j - CP)];
-      pm[j] = msum;
+      for (int j = 0; j < SYNC_V; j++) {
+        msum += Mv[j] - ms[mo + j];
+        pm[j] = msum;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SYNC_V; j++) {
+        msum += Mv[j] - ms[sync_lp(HM + SYNC_V * tid + j - CP)];
+        pm[j] = msum;
+      }
     }
     float manc = 0.f;
     for (int m = -CP + tid; m < 0; m += SYNC_THREADS) manc += ms[sync_lp(HM + m)];
@@ -650,13 +659,23 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     int nv = 0;
     unsigned amask = 0;  // approximate candidates
     float floc = 0.f;
+    const float athr = p.cand_thr - SYNC_GUARD;
+    if (t0 + (uint64_t)T <= p.nsamples) {
+      nv = SYNC_V;
 #pragma unroll
-    for (int j = 0; j < SYNC_V; j++) {
-      const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
-      if (n < p.nsamples) {
-        nv++;
+      for (int j = 0; j < SYNC_V; j++) {
         floc = fmaf(floc, decay_f, p.alpha * u[j]);
-        if (u[j] > p.cand_thr - SYNC_GUARD) amask |= 1u << j;
+        amask |= (u[j] > athr) ? (1u << j) : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SYNC_V; j++) {
+        const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
+        if (n < p.nsamples) {
+          nv++;
+          floc = fmaf(floc, decay_f, p.alpha * u[j]);
+          if (u[j] > athr) amask |= 1u << j;
+        }
       }
     }
     float wgt = wfull;
@@ -690,9 +709,11 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     }
     __syncthreads();
     const int amin = rng[0], bmax = rng[1];
+    STAMP(8);
     // ---- 7. fixed-point re-evaluation of [amin, bmax] (normative arithmetic) ------------------
     c32* Pe = xs + sync_lp(p.HX) + 8;  // scratch: the x tile is dead (history already saved)
     sync_exact_range(ys, me, ue, Pe, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid, p.tapcp);
+    STAMP(9);
 
     // ---- 8. candidates: maximal runs of (exact) u > theta inside the tile ----------------------
     unsigned cmask = 0;
@@ -814,10 +835,11 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       piece_left -= (uint32_t)npieces;
     }
     __syncthreads();  // Pe / ue / me are scratch that the next iteration overwrites
+    STAMP(10);
   }
 #ifdef SYNC_STAMPS
   if (p.stamps && threadIdx.x == 0)
-    for (int i = 0; i < 8; i++) p.stamps[blockIdx.x * 8 + i] = st_acc[i];
+    for (int i = 0; i < 12; i++) p.stamps[blockIdx.x * 12 + i] = st_acc[i];
 #endif
 }
 
