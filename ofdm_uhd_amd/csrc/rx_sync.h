@@ -245,11 +245,11 @@ __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scra
 // Normative (Q23.40) evaluation of u = Mbar - 1 for the tile-relative samples [amin, bmax]:
 //   me[k]  exact M of sample amin-CP+1+k        (k < bmax-amin+CP)
 //   ue[k]  exact u of sample amin+k
-//   Pe[k]  exact P of sample amin+k
+//   gP[k]  exact P of sample amin+k, gU[k] its u: written straight to the candidate arrays (global)
 // Rare path (only where the float32 pre-selection found something): kept out of line so that it
 // does not weigh on the register allocation of the streaming loop.
 // ---------------------------------------------------------------------------------
-__device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* ue, c32* Pe, long long* sc_i64, int amin,
+__device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* ue, c32* gP, float* gU, long long* sc_i64, int amin,
                                               int bmax, int D, int CP, int HY, int64_t t0s, int64_t qvalid, int64_t mvalid,
                                               float tapcp) {
   const int tid = threadIdx.x;
@@ -306,7 +306,7 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
     if (!(mm <= 1024.0f)) mm = 1024.0f;
     if (t0s + m < mvalid) mm = 0.0f;
     me[k] = mm;
-    if (m >= amin) Pe[m - amin] = mk(pre, pim);
+    if (m >= amin) gP[m - amin] = mk(pre, pim);
   }
   __syncthreads();
   // (iii) exact CP-length moving sum of M over [amin, bmax]; me[k] holds sample s0+1+k = amin-CP+1+k
@@ -323,7 +323,9 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
   for (int jj = j0; jj < j1; jj++) {
     if (jj > 0) wm += q40_from_float(me[CP - 1 + jj]) - q40_from_float(me[jj - 1]);
     const float mbar = (float)(q40_to_double(wm) * (double)tapcp);
-    ue[jj] = mbar + (-1.0f);
+    const float ux = mbar + (-1.0f);
+    ue[jj] = ux;
+    gU[jj] = ux;
   }
   __syncthreads();
 #undef QTERM
@@ -710,9 +712,27 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     __syncthreads();
     const int amin = rng[0], bmax = rng[1];
     STAMP(8);
-    // ---- 7. fixed-point re-evaluation of [amin, bmax] (normative arithmetic) ------------------
-    c32* Pe = xs + sync_lp(p.HX) + 8;  // scratch: the x tile is dead (history already saved)
-    sync_exact_range(ys, me, ue, Pe, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid, p.tapcp);
+    // ---- 7. fixed-point re-evaluation of [amin, bmax] (normative arithmetic); the whole range is
+    //         stored as this tile's candidate values (u, P), pieces then point into it -------------------
+    const int rlen = bmax - amin + 1;
+    if ((uint32_t)rlen > cand_left) {
+      if (tid == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);  // rare: fresh chunk
+      __syncthreads();
+      cand_base = bc[0];
+      cand_left = SYNC_CHUNK_C;
+      __syncthreads();
+    }
+    const unsigned long long cbase = cand_base;
+    bool fits = cbase + (unsigned long long)rlen <= p.cand_cap;
+    cand_base += (unsigned long long)rlen;
+    cand_left -= (uint32_t)rlen;
+    if (fits) {
+      sync_exact_range(ys, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid,
+                       p.tapcp);
+    } else {
+      for (int i = tid; i < rlen; i += SYNC_THREADS) ue[i] = -1.0f;  // nothing can be stored: no candidates
+      __syncthreads();
+    }
     STAMP(9);
 
     // ---- 8. candidates: maximal runs of (exact) u > theta inside the tile ----------------------
@@ -783,27 +803,20 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     const int packed = (__popc(startmask) << 16) | __popc(cmask);
     int ptot;
     const int pex = block_excl_scan_add<int>(packed, sc_i32, &ptot);
-    const int nstart_before = pex >> 16, ncand_before = pex & 0xFFFF;
+    const int nstart_before = pex >> 16;
     const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
-    if ((uint32_t)ncand > cand_left || (uint32_t)npieces > piece_left) {
-      // rare: take fresh chunks (what is left of the old ones is simply not used)
-      if (tid == 0) {
-        bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);
-        bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);
-      }
+    if ((uint32_t)npieces > piece_left) {
+      if (tid == 0) bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);  // rare: fresh chunk
       __syncthreads();
-      cand_base = bc[0];
       piece_base = bc[1];
-      cand_left = SYNC_CHUNK_C;
       piece_left = SYNC_CHUNK_P;
     }
-    const unsigned long long basev = cand_base, basep = piece_base;
-    const bool fits = (basev + SYNC_CHUNK_C <= p.cand_cap + cand_left) && (basep + SYNC_CHUNK_P <= p.piece_cap + piece_left) &&
-                      (basev + (unsigned long long)ncand <= p.cand_cap) && (basep + (unsigned long long)npieces <= p.piece_cap);
+    const unsigned long long basep = piece_base;
+    fits = fits && (basep + (unsigned long long)npieces <= p.piece_cap);
     if (!fits && tid == 0) atomicOr(p.overflow, 1u);
     if (fits && ncand > 0) {
       double a_loc = pre.b;  // zero-init average just before this thread's first sample
-      int so = nstart_before, co = ncand_before;
+      int so = nstart_before;
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
         const int i = SYNC_V * tid + j;
@@ -811,14 +824,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         if ((startmask >> j) & 1u) {
           SyncPiece* pc = p.pieces + basep + so;
           pc->start = n;
-          pc->val_off = basev + (unsigned long long)co;
+          pc->val_off = cbase + (unsigned long long)(i - amin);
           pc->bloc = a_loc;
           so++;
-        }
-        if ((cmask >> j) & 1u) {
-          p.cand_u[basev + co] = u[j];
-          p.cand_P[basev + co] = Pe[i - amin];
-          co++;
         }
         if ((endmask >> j) & 1u) p.pieces[basep + so - 1].end = n;
         if (j < nv) a_loc = (double)p.alpha * (double)u[j] + p.decay * a_loc;
@@ -829,12 +837,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       p.tile_first[tile] = basep;
     }
     if (fits) {
-      cand_base += (unsigned long long)ncand;
       piece_base += (unsigned long long)npieces;
-      cand_left -= (uint32_t)ncand;
       piece_left -= (uint32_t)npieces;
     }
-    __syncthreads();  // Pe / ue / me are scratch that the next iteration overwrites
+    __syncthreads();  // ue / me are scratch that the next iteration overwrites
     STAMP(10);
   }
 #ifdef SYNC_STAMPS
