@@ -31,6 +31,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
+# BASELINE.json configs that fit one GPU.  c2 is the headline (configs[1]); c3 / c5 use the largest legal packet
+# (4 091-byte payload); c5's occ / CP are the survey's defaults (BASELINE gives only N and the modulation).
+CONFIGS = {
+    "c2": dict(N=512, occ=200, CP=128, mod="qpsk", size=1026, packets=65536, snr=30.0,
+               name="N_fft=512, occ=200, QPSK, CP=128, synthetic AWGN channel (BASELINE configs[1])"),
+    "c3": dict(N=2048, occ=1200, CP=512, mod="qam16", size=4091, packets=16384, snr=40.0,
+               name="N_fft=2048, occ=1200, 16-QAM, CP=512 (BASELINE configs[2])"),
+    "c5": dict(N=4096, occ=2400, CP=1024, mod="qam64", size=4091, packets=16384, snr=45.0,
+               name="N_fft=4096, occ=2400, 64-QAM, CP=1024, no sensing tap (BASELINE configs[4] sizing)"),
+}
+
 
 def make_payload_blob(npkt, size, stream_id):
     """payload = !H pktno | !H 0 | data (benchmark_ofdm_tx.py:117); data from PCG64(0x0FD30000 + stream)."""
@@ -74,10 +85,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--packets", type=int, default=65536, help="packets per stream per step")
-    ap.add_argument("--size", type=int, default=1026, help="payload bytes (4-byte prefix + 1022 data)")
-    ap.add_argument("--snr", type=float, default=30.0)
+    ap.add_argument("--packets", type=int, default=None, help="packets per stream per step (default: per config)")
+    ap.add_argument("--size", type=int, default=None, help="payload bytes (default: per config)")
+    ap.add_argument("--snr", type=float, default=None)
     ap.add_argument("--cpu-packets", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="BASELINE.json config to run (default c2 = configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
 
     import torch
@@ -92,7 +105,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    N, occ, CP, mod = 512, 200, 128, "qpsk"
+    cfgd = CONFIGS[args.config]
+    N, occ, CP, mod = cfgd["N"], cfgd["occ"], cfgd["CP"], cfgd["mod"]
+    if args.packets is None:
+        args.packets = cfgd["packets"]
+    if args.size is None:
+        args.size = cfgd["size"]
+    if args.snr is None:
+        args.snr = cfgd["snr"]
     opt = options.default_options(modulation=mod, fft_length=N, occupied_tones=occ, cp_length=CP, tx_amplitude=0.25)
     cfg = config.make_cfg(opt, device_ptrs=True, device_id=local_rank)
     eng = engine.Engine(cfg=cfg)
@@ -100,8 +120,9 @@ def main():
     P, size = args.packets, args.size
     stream_id = rank
     ncar = len(config.carrier_map(occ, N))
-    # mean in-packet power: ncar unit-power carriers through IFFT/sqrt(N), amplitude 0.25, |QPSK point|^2 = 0.9997
-    psig = ncar / float(N) * 0.25 ** 2 * abs(config.rotated_constellation(mod)[0]) ** 2
+    # mean in-packet power: ncar carriers of mean constellation power through IFFT/sqrt(N), amplitude 0.25
+    cpow = float(np.mean(np.abs(np.array(config.rotated_constellation(mod))) ** 2))
+    psig = ncar / float(N) * 0.25 ** 2 * cpow
     sigma = float(np.sqrt(psig / 10 ** (args.snr / 10.0)))
     lead, tail = 2 * N, L + 2 * N
     eng.set_channel(sigma=sigma, cfo=0.0, seed=0xC0FFEE, stream_id=stream_id, lead=lead, tail=tail)
@@ -164,12 +185,14 @@ def main():
         # algorithmic bytes of ONE launch of that kernel (DESIGN.md "Roofline accounting"):
         #   k_sync / k_rx_demod : the compulsory read of the received stream, (N+CP)*8 B per symbol
         #   k_tx_mod            : the compulsory write of the stream + the packet bits in
-        per_symbol = {"k_sync": L * 8.0, "k_rx_demod": L * 8.0 + ncar * 2 / 8.0,
-                      "k_tx_mod": L * 8.0 + ncar * 2 / 8.0}.get(kname, L * 8.0)
+        nbits = int(np.ceil(np.log2(cfg.arity)))
+        bits_b = ncar * nbits / 8.0                                    # payload bits of one symbol, in bytes
+        per_symbol = {"k_sync": L * 8.0, "k_rx_demod": N * 8.0 + bits_b,
+                      "k_tx_mod": L * 8.0 + bits_b}.get(kname, L * 8.0)
         launch_bytes = per_symbol * nsym
         avg_s = (kms / max(klaunch, 1)) * 1e-3
         achieved = launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        path_bytes = 2 * L * 8.0 + 2 * ncar * 2 / 8.0               # 10 339 B per symbol at C2
+        path_bytes = 2 * L * 8.0 + 2 * bits_b                        # 10 339 B per symbol at C2
         out = {
             "metric": "OFDM symbols/sec (TX+loopback RX) @ N_fft=512; packet CRC pass rate",
             "value": sym_per_s,
@@ -183,7 +206,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "N_fft=512, occ=200, QPSK, CP=128, synthetic AWGN channel (BASELINE configs[1])",
+            "config": {"workload": cfgd["name"],
                        "packets_per_stream_per_step": P, "payload_bytes": size, "symbols_per_packet": nsym // P,
                        "snr_db": args.snr, "streams": world, "parallelism": "independent streams, 1 per GPU"},
             "crc_pass_rate": g["crc_ok"] / float(max(world * P * args.steps, 1)),

@@ -397,8 +397,6 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   const float decay_f = (float)p.decay;
   const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
   // LDS indices of this thread's 8 consecutive samples (HX, HY, D multiples of 8: lp(8g + r) = 9g + r)
-  const int gb = sync_lp(p.HX + SYNC_V * tid - 8);
-  const int yb = sync_lp(HY + SYNC_V * tid), yb1 = sync_lp(HY - D + SYNC_V * tid), yb2 = sync_lp(HY - 2 * D + SYNC_V * tid);
   float4 xpre[SYNC_V / 2];
   bool have_pre = false;
   // current allocation chunks of this workgroup (uniform across the block)
@@ -407,6 +405,12 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   __syncthreads();
 
   for (uint64_t tile = tile_first; tile < tile_own1; tile++) {
+    // Opaque copy of the thread index, renewed every tile: otherwise the compiler hoists every
+    // tid-dependent LDS address of the loop body out of the loop and then spills them.
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int gb = sync_lp(p.HX + SYNC_V * tl - 8);
+    const int yb = sync_lp(HY + SYNC_V * tl), yb1 = sync_lp(HY - D + SYNC_V * tl), yb2 = sync_lp(HY - 2 * D + SYNC_V * tl);
     const uint64_t t0 = tile * (uint64_t)T;
     const int64_t t0s = (int64_t)t0;
     const bool owned = tile >= tile_own0;
@@ -418,7 +422,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     if (have_pre) {
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) {
-        const int pi = tid + r * SYNC_THREADS;  // pair index
+        const int pi = tl + r * SYNC_THREADS;  // pair index
         const int li = sync_lp(p.HX + 2 * pi);
         xs[li] = mk(xpre[r].x, xpre[r].y);
         xs[li + 1] = mk(xpre[r].z, xpre[r].w);
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       const float4* src = reinterpret_cast<const float4*>(p.x + t0);
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) {
-        const int pi = tid + r * SYNC_THREADS;
+        const int pi = tl + r * SYNC_THREADS;
         const float4 v = src[pi];
         const int li = sync_lp(p.HX + 2 * pi);
         xs[li] = mk(v.x, v.y);
@@ -436,7 +440,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     } else {
 #pragma unroll
       for (int r = 0; r < SYNC_V; r++) {
-        const int i = tid + r * SYNC_THREADS;
+        const int i = tl + r * SYNC_THREADS;
         const uint64_t n = t0 + (uint64_t)i;
         c32 v = mk(0.f, 0.f);
         if (n < p.nsamples) v = p.x[n];
@@ -444,25 +448,25 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       }
     }
     if (HY <= T) {
-      for (int i = tid; i < HY; i += SYNC_THREADS) ys[sync_lp(i)] = ys[sync_lp(i + T)];
+      for (int i = tl; i < HY; i += SYNC_THREADS) ys[sync_lp(i)] = ys[sync_lp(i + T)];
     } else {
       for (int off = 0; off < HY; off += T) {  // overlapping ranges: chunk by chunk
         c32 v[SYNC_V];
 #pragma unroll
         for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
+          const int i = off + tl + r * SYNC_THREADS;
           if (i < HY && i < off + T) v[r] = ys[sync_lp(i + T)];
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tid + r * SYNC_THREADS;
+          const int i = off + tl + r * SYNC_THREADS;
           if (i < HY && i < off + T) ys[sync_lp(i)] = v[r];
         }
         __syncthreads();
       }
     }
-    for (int i = tid; i < HM; i += SYNC_THREADS) ms[sync_lp(i)] = ms[sync_lp(i + T)];  // HM <= T (checked by the host)
+    for (int i = tl; i < HM; i += SYNC_THREADS) ms[sync_lp(i)] = ms[sync_lp(i + T)];  // HM <= T (checked by the host)
     __syncthreads();  // B1
     STAMP(0);
 
@@ -471,7 +475,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     if (tile + 1 < tile_own1 && x_al16 && t0 + 2ull * T <= p.nsamples) {
       const float4* src = reinterpret_cast<const float4*>(p.x + t0 + T);
 #pragma unroll
-      for (int r = 0; r < SYNC_V / 2; r++) xpre[r] = src[tid + r * SYNC_THREADS];
+      for (int r = 0; r < SYNC_V / 2; r++) xpre[r] = src[tl + r * SYNC_THREADS];
       have_pre = true;
     }
 
@@ -520,7 +524,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     __syncthreads();  // B2
     STAMP(2);
     // x history for the next tile: [T, T+HX) -> [0, HX) (disjoint, T >= HX); the rest of xs is scratch from here on
-    for (int i = tid; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
+    for (int i = tl; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
 
     // ---- 3. y to HBM (owned tiles only), coalesced from LDS ----------------------------
     if (owned && !(p.ablate & 4)) {
@@ -528,7 +532,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         float4* dst = reinterpret_cast<float4*>(p.y + t0);
 #pragma unroll
         for (int r = 0; r < SYNC_V / 2; r++) {
-          const int pi = tid + r * SYNC_THREADS;
+          const int pi = tl + r * SYNC_THREADS;
           const int li = sync_lp(HY + 2 * pi);
           const c32 a = ys[li], b = ys[li + 1];
           dst[pi] = make_float4(a.re, a.im, b.re, b.im);
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       } else {
 #pragma unroll
         for (int r = 0; r < SYNC_V; r++) {
-          const int i = tid + r * SYNC_THREADS;
+          const int i = tl + r * SYNC_THREADS;
           const uint64_t n = t0 + (uint64_t)i;
           if (n < p.nsamples) p.y[n] = ys[sync_lp(HY + i)];
         }
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         pfe[j] = tsum.c;
       }
       // anchor: the window sums at the sample before the tile, summed afresh from the history
-      for (int m = -D + tid; m < 0; m += SYNC_THREADS) {
+      for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
         const c32 a = ys[sync_lp(HY + m)];
         const c32 d1 = ys[sync_lp(HY + m - D)];
         anc.a += fmaf(a.re, d1.re, a.im * d1.im);
@@ -575,7 +579,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     } else {
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
-        const int64_t n = t0s + SYNC_V * tid + j;
+        const int64_t n = t0s + SYNC_V * tl + j;
         const c32 a = ys[yb + j];
         const c32 d1 = ys[yb1 + j];
         const c32 d2 = ys[yb2 + j];
@@ -597,7 +601,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         pfi[j] = tsum.b;
         pfe[j] = tsum.c;
       }
-      for (int m = -D + tid; m < 0; m += SYNC_THREADS) {
+      for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
         if (t0s + m >= qvalid) {
           const c32 a = ys[sync_lp(HY + m)];
           const c32 d1 = ys[sync_lp(HY + m - D)];
@@ -612,7 +616,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     block_scan3_sum3(tsum, anc, scA, &ex3, &anch);  // B3
     STAMP(4);
     float Mv[SYNC_V];
-    const int mb = sync_lp(HM + SYNC_V * tid);
+    const int mb = sync_lp(HM + SYNC_V * tl);
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
       const float pre = anch.a + ex3.a + pfr[j];
@@ -622,7 +626,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       const float den = r * r;
       float m = (den > 0.0f) ? __fdividef(num, den) : 0.0f;
       if (!(m <= 1024.0f)) m = 1024.0f;
-      if (masked && (t0s + SYNC_V * tid + j < mvalid)) m = 0.0f;
+      if (masked && (t0s + SYNC_V * tl + j < mvalid)) m = 0.0f;
       Mv[j] = m;
       ms[mb + j] = m;
     }
@@ -633,7 +637,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     float pm[SYNC_V];
     float msum = 0.f;
     if ((CP & 7) == 0) {  // (HM - CP) is a multiple of 8: one base index, constant offsets
-      const int mo = sync_lp(HM - CP + SYNC_V * tid);
+      const int mo = sync_lp(HM - CP + SYNC_V * tl);
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
         msum += Mv[j] - ms[mo + j];
@@ -642,12 +646,12 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     } else {
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
-        msum += Mv[j] - ms[sync_lp(HM + SYNC_V * tid + j - CP)];
+        msum += Mv[j] - ms[sync_lp(HM + SYNC_V * tl + j - CP)];
         pm[j] = msum;
       }
     }
     float manc = 0.f;
-    for (int m = -CP + tid; m < 0; m += SYNC_THREADS) manc += ms[sync_lp(HM + m)];
+    for (int m = -CP + tl; m < 0; m += SYNC_THREADS) manc += ms[sync_lp(HM + m)];
     float mex, mach;
     block_scan1_sum1(msum, manc, scB, &mex, &mach);  // B5
     STAMP(6);
@@ -672,7 +676,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     } else {
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
-        const uint64_t n = t0 + (uint64_t)(SYNC_V * tid + j);
+        const uint64_t n = t0 + (uint64_t)(SYNC_V * tl + j);
         if (n < p.nsamples) {
           nv++;
           floc = fmaf(floc, decay_f, p.alpha * u[j]);
@@ -683,7 +687,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     float wgt = wfull;
     if (t0 + (uint64_t)T > p.nsamples) {
       // the (short) last tile: weight by the samples that follow this thread's
-      const int64_t after = (int64_t)(p.nsamples - t0) - (int64_t)(SYNC_V * tid + nv);
+      const int64_t after = (int64_t)(p.nsamples - t0) - (int64_t)(SYNC_V * tl + nv);
       wgt = (float)pow(p.decay, (double)(after > 0 ? after : 0));
     }
     if (p.exact_all) amask = (1u << nv) - 1u;
@@ -693,21 +697,21 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     }
     const int anyc = __syncthreads_or(amask != 0);  // B6
     STAMP(7);
-    if (tid == 0) {
+    if (tl == 0) {
       p.tile_B[tile] = (double)((scC[0] + scC[1]) + (scC[2] + scC[3]));
       if (!anyc) p.tile_npieces[tile] = 0;
     }
     if (!anyc) continue;
 
     // ================= rare path: something near the threshold in this tile =================
-    if (tid == 0) {
+    if (tl == 0) {
       rng[0] = T;
       rng[1] = -1;
     }
     __syncthreads();
     if (amask) {
-      atomicMin(&rng[0], SYNC_V * tid + __ffs(amask) - 1);
-      atomicMax(&rng[1], SYNC_V * tid + 31 - __clz(amask));
+      atomicMin(&rng[0], SYNC_V * tl + __ffs(amask) - 1);
+      atomicMax(&rng[1], SYNC_V * tl + 31 - __clz(amask));
     }
     __syncthreads();
     const int amin = rng[0], bmax = rng[1];
@@ -716,7 +720,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     //         stored as this tile's candidate values (u, P), pieces then point into it -------------------
     const int rlen = bmax - amin + 1;
     if ((uint32_t)rlen > cand_left) {
-      if (tid == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);  // rare: fresh chunk
+      if (tl == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);  // rare: fresh chunk
       __syncthreads();
       cand_base = bc[0];
       cand_left = SYNC_CHUNK_C;
@@ -730,7 +734,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       sync_exact_range(ys, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid,
                        p.tapcp);
     } else {
-      for (int i = tid; i < rlen; i += SYNC_THREADS) ue[i] = -1.0f;  // nothing can be stored: no candidates
+      for (int i = tl; i < rlen; i += SYNC_THREADS) ue[i] = -1.0f;  // nothing can be stored: no candidates
       __syncthreads();
     }
     STAMP(9);
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     unsigned cmask = 0;
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
-      const int i = SYNC_V * tid + j;
+      const int i = SYNC_V * tl + j;
       if (j < nv && i >= amin && i <= bmax) {
         const float ux = ue[i - amin];
         u[j] = ux;
@@ -772,7 +776,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         sc_f64[2 * w + 1] = inc.b;
       }
     }
-    cm[tid] = (unsigned char)cmask;
+    cm[tl] = (unsigned char)cmask;
     __syncthreads();
     Aff pre;
     pre.A = 1.0;
@@ -794,8 +798,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       }
       pre = aff_then(pre, prev);
     }
-    const unsigned prevbit = (tid > 0) ? ((cm[tid - 1] >> 7) & 1u) : 0u;
-    const unsigned nextbit = (tid < SYNC_THREADS - 1) ? (cm[tid + 1] & 1u) : 0u;
+    const unsigned prevbit = (tl > 0) ? ((cm[tl - 1] >> 7) & 1u) : 0u;
+    const unsigned nextbit = (tl < SYNC_THREADS - 1) ? (cm[tl + 1] & 1u) : 0u;
     const unsigned ext = (cmask << 1) | prevbit;           // bit j+1 = cand[j], bit 0 = cand[-1]
     const unsigned startmask = cmask & ~ext & 0xFFu;       // cand[j] && !cand[j-1]
     const unsigned extn = (cmask >> 1) | (nextbit << 7);   // bit j = cand[j+1]
@@ -806,20 +810,20 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     const int nstart_before = pex >> 16;
     const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
     if ((uint32_t)npieces > piece_left) {
-      if (tid == 0) bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);  // rare: fresh chunk
+      if (tl == 0) bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);  // rare: fresh chunk
       __syncthreads();
       piece_base = bc[1];
       piece_left = SYNC_CHUNK_P;
     }
     const unsigned long long basep = piece_base;
     fits = fits && (basep + (unsigned long long)npieces <= p.piece_cap);
-    if (!fits && tid == 0) atomicOr(p.overflow, 1u);
+    if (!fits && tl == 0) atomicOr(p.overflow, 1u);
     if (fits && ncand > 0) {
       double a_loc = pre.b;  // zero-init average just before this thread's first sample
       int so = nstart_before;
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
-        const int i = SYNC_V * tid + j;
+        const int i = SYNC_V * tl + j;
         const uint64_t n = t0 + (uint64_t)i;
         if ((startmask >> j) & 1u) {
           SyncPiece* pc = p.pieces + basep + so;
@@ -832,7 +836,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         if (j < nv) a_loc = (double)p.alpha * (double)u[j] + p.decay * a_loc;
       }
     }
-    if (tid == 0) {
+    if (tl == 0) {
       p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
       p.tile_first[tile] = basep;
     }
