@@ -168,6 +168,51 @@ int ofdm_rx(ofdm_handle *h, const ofdm_c32 *iq, uint64_t nsamples, uint8_t *payl
             uint32_t *payload_len /* max_pkts, host */, uint8_t *crc_ok /* max_pkts, host */,
             int max_pkts, int *npkt, ofdm_stats *stats /* may be NULL */);
 
+/* --- spectrum sensing: the `sensor` flowgraph + sense_loop + hex_conv
+ *     (predictive_sense.py:72-123,150-268; same code in sensing_and_tramsmitting*.py) ---
+ * stream_to_vector(fft_size) -> fft_vcc(fft_size, True, window) -> complex_to_mag_squared
+ * -> bin_statistics_f(fft_size, msgq, tune, tune_delay, dwell_delay): after every retune
+ * tune_delay vectors are discarded, then the per-bin MAX over dwell_delay vectors is
+ * posted as one message (float32[fft_size], FFT order).  sense_loop then sums avg_msgs
+ * messages in float64 (:168-172), consumes skip_msgs more without using them (the message
+ * that reaches the else branch, :174), divides by avg_msgs (:175-176), thresholds
+ * (bit = 0 if mean > threshold else 1, :179), swaps the halves into ascending-frequency
+ * order (:193-205) and packs nibbles LSB-first into upper-case hex (hex_conv :235-268). */
+#define OFDM_SENSE_MAX_FFT 4096
+typedef struct ofdm_sense_cfg {
+  uint32_t struct_size;    /* = sizeof(ofdm_sense_cfg) */
+  uint32_t fft_size;       /* power of two, 64..4096 (-s/--fft-size, default 256) */
+  uint32_t tune_delay;     /* vectors dropped per message period (>= 0)           */
+  uint32_t dwell_delay;    /* vectors max-held per message (>= 1)                 */
+  uint32_t avg_msgs;       /* messages averaged per decision (10)                 */
+  uint32_t skip_msgs;      /* messages consumed unused per decision (1)           */
+  double threshold;        /* 1e-4 (:179); 1e-3 / 0.2 in the secondary_tx variants */
+  float window[OFDM_SENSE_MAX_FFT]; /* fft_vcc window taps (window.blackmanharris) */
+} ofdm_sense_cfg;
+
+/* how many messages / decisions a stream of nsamples yields */
+int ofdm_sense_count(const ofdm_sense_cfg *sc, uint64_t nsamples, uint64_t *nmsgs, uint64_t *ndecisions);
+/* iq follows OFDM_F_DEVICE_PTRS; every output is HOST memory and may be NULL:
+ * msgs[nmsgs][fft_size] (bin_statistics_f message bodies, FFT order), then per decision
+ * mean_inorder[fft_size] (float64, ascending frequency), bits_inorder[fft_size] (0/1),
+ * hex[fft_size/4] (no terminator). */
+int ofdm_sense(ofdm_handle *h, const ofdm_sense_cfg *sc, const ofdm_c32 *iq, uint64_t nsamples,
+               float *msgs, uint64_t msgs_cap /* messages */, double *mean_inorder, uint8_t *bits_inorder,
+               char *hex, uint64_t dec_cap /* decisions */, uint64_t *nmsgs, uint64_t *ndecisions);
+/* sense_loop alone (:150-222) over ready-made message bodies msgs[nmsgs][fft_size]
+ * (HOST memory, e.g. drained from a real gr.msg_queue): same three decision outputs. */
+int ofdm_sense_decide(ofdm_handle *h, const ofdm_sense_cfg *sc, const float *msgs, uint64_t nmsgs,
+                      double *mean_inorder, uint8_t *bits_inorder, char *hex, uint64_t dec_cap,
+                      uint64_t *ndecisions);
+/* fuse the sensor into ofdm_rx (BASELINE config 5): while set, every ofdm_rx call also
+ * runs the sensing kernels over the same IQ buffer on a second stream, overlapped with
+ * the receiver; fetch the outcome of the last call with ofdm_rx_sense_result (same
+ * outputs as ofdm_sense).  sc == NULL switches it off. */
+int ofdm_set_rx_sense(ofdm_handle *h, const ofdm_sense_cfg *sc);
+int ofdm_rx_sense_result(ofdm_handle *h, float *msgs, uint64_t msgs_cap, double *mean_inorder,
+                         uint8_t *bits_inorder, char *hex, uint64_t dec_cap, uint64_t *nmsgs,
+                         uint64_t *ndecisions);
+
 /* --- debug taps: the reference's --log probe points (ofdm.py:123-131,253-254;
  *     ofdm_receiver.py~:144-152).  Enable before the call, read after.  Output
  *     is always copied to HOST memory. ---------------------------------------- */
@@ -197,7 +242,8 @@ enum {
   OFDM_K_PEAK = 4,  /* peak detector / sampler / NCO bookkeeping             */
   OFDM_K_DEMOD = 5, /* derotate + FFT + frame acquisition + frame sink       */
   OFDM_K_DEFRAME = 6, /* dewhiten + CRC check + output compaction            */
-  OFDM_K_COUNT = 7
+  OFDM_K_SENSE = 7, /* windowed FFT + |.|^2 + max-hold (+ decision tail)    */
+  OFDM_K_COUNT = 8
 };
 int ofdm_prof_enable(ofdm_handle *h, int on);
 int ofdm_prof_reset(ofdm_handle *h);

@@ -27,7 +27,8 @@ OFDM_F_PAD_FOR_USRP = 1 << 1
 (TAP_TX_PACKETS, TAP_TX_FREQ, TAP_RX_CHAN_FILT, TAP_RX_METRIC, TAP_RX_PEAKS, TAP_RX_ANGLES,
  TAP_RX_FRAMES, TAP_RX_FFT, TAP_RX_ACQ, TAP_RX_SINK, TAP_RX_PACKETS, TAP_COUNT) = range(12)
 
-(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_COUNT) = range(8)
+(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_COUNT) = range(9)
+OFDM_SENSE_MAX_FFT = 4096
 
 
 class ofdm_c32(C.Structure):
@@ -82,13 +83,27 @@ class ofdm_stats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class ofdm_sense_cfg(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("fft_size", C.c_uint32),
+        ("tune_delay", C.c_uint32),
+        ("dwell_delay", C.c_uint32),
+        ("avg_msgs", C.c_uint32),
+        ("skip_msgs", C.c_uint32),
+        ("threshold", C.c_double),
+        ("window", C.c_float * OFDM_SENSE_MAX_FFT),
+    ]
+
+
 # every symbol include/ofdm_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "ofdm_abi_version", "ofdm_device_count", "ofdm_create", "ofdm_destroy", "ofdm_last_error",
     "ofdm_set_stream", "ofdm_set_tx_amplitude", "ofdm_set_channel", "ofdm_framed_len",
     "ofdm_make_packets", "ofdm_tx_frame_count", "ofdm_tx", "ofdm_channel", "ofdm_rx",
     "ofdm_set_taps", "ofdm_tap", "ofdm_prof_enable", "ofdm_prof_reset", "ofdm_prof_get",
-    "ofdm_kernel_name",
+    "ofdm_kernel_name", "ofdm_sense_count", "ofdm_sense", "ofdm_sense_decide", "ofdm_set_rx_sense",
+    "ofdm_rx_sense_result",
 )
 
 _LIB = None
@@ -124,6 +139,12 @@ def _declare(lib):
     lib.ofdm_prof_get.argtypes = [H, C.c_int, C.POINTER(C.c_double), u64p]
     lib.ofdm_kernel_name.argtypes = [C.c_int]
     lib.ofdm_kernel_name.restype = C.c_char_p
+    SC = C.POINTER(ofdm_sense_cfg)
+    lib.ofdm_sense_count.argtypes = [SC, C.c_uint64, u64p, u64p]
+    lib.ofdm_sense.argtypes = [H, SC, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p, u64p]
+    lib.ofdm_sense_decide.argtypes = [H, SC, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
+    lib.ofdm_set_rx_sense.argtypes = [H, SC]
+    lib.ofdm_rx_sense_result.argtypes = [H, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p, u64p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("ofdm_abi_version", "ofdm_device_count"):

@@ -154,3 +154,32 @@ def make_cfg(options, pad_for_usrp=False, device_ptrs=False, device_id=0, pad_se
     cfg.whitener_offset = 0
     cfg.pad_seed = int(pad_seed)
     return cfg
+
+
+def make_sense_cfg(fft_size=256, tune_delay=24, dwell_delay=244, avg_msgs=10, skip_msgs=1, threshold=0.00010,
+                   window=None):
+    """ofdm_sense_cfg for the `sensor` flowgraph of predictive_sense.py:72-123 and its
+    sense_loop (:150-222).  Defaults are the reference's: --fft-size 256 (:50),
+    tune/dwell 1 ms / 10 ms at 6.25 MS/s in FFT frames (:113-116), 10 messages averaged
+    (:159) with the 11th consumed unused (:174), threshold 1e-4 (:179)."""
+    from . import window as _window
+    n = int(fft_size)
+    if n < 64 or n > _abi.OFDM_SENSE_MAX_FFT or (n & (n - 1)):
+        raise ValueError("fft_size must be a power of two in [64, %d]" % _abi.OFDM_SENSE_MAX_FFT)
+    if int(dwell_delay) < 1 or int(tune_delay) < 0 or int(avg_msgs) < 1 or int(skip_msgs) < 0:
+        raise ValueError("dwell_delay >= 1, tune_delay >= 0, avg_msgs >= 1, skip_msgs >= 0")
+    w = _window.blackmanharris(n) if window is None else list(window)
+    if len(w) != n:
+        # gr_fft_vcc_fftw::set_window refuses a window of the wrong length
+        raise ValueError("window must have fft_size taps")
+    sc = _abi.ofdm_sense_cfg()
+    sc.struct_size = ctypes.sizeof(_abi.ofdm_sense_cfg)
+    sc.fft_size = n
+    sc.tune_delay = int(tune_delay)
+    sc.dwell_delay = int(dwell_delay)
+    sc.avg_msgs = int(avg_msgs)
+    sc.skip_msgs = int(skip_msgs)
+    sc.threshold = float(threshold)
+    for i, v in enumerate(w):
+        sc.window[i] = v
+    return sc

@@ -15,6 +15,7 @@
 #include "tx.h"
 #include "rx_sync.h"
 #include "rx_demod.h"
+#include "sense.h"
 
 static std::string g_create_error;
 
@@ -32,6 +33,19 @@ static std::string g_create_error;
     (h)->err = (msg);      \
     return (code);         \
   } while (0)
+
+// spectrum-sensor workspaces (sense.h / engine_sense.inc)
+struct SenseState {
+  DevBuf d_win, d_tw, d_msgs, d_mean, d_bits, d_hex, x_stage;
+  std::vector<float> tab_win;  // window the device tables were built from
+  int tab_S = 0;
+  int S = 0;
+  uint64_t nm = 0, nd = 0;     // messages / decisions of the last run
+  bool rx_on = false;          // fused into ofdm_rx
+  ofdm_sense_cfg rx_cfg;
+  hipStream_t side = nullptr;  // sensing runs beside the receiver on this stream
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+};
 
 struct ofdm_handle {
   ofdm_cfg cfg;
@@ -61,6 +75,7 @@ struct ofdm_handle {
   Profiler prof;
 
   RxState rx;  // receive-side workspaces (rx_demod.h)
+  SenseState sense;
 };
 
 // ------------------------------------------------------------------------------
@@ -175,7 +190,7 @@ extern "C" const char* ofdm_last_error(const ofdm_handle* h) { return h ? h->err
 
 extern "C" const char* ofdm_kernel_name(int k) {
   static const char* names[OFDM_K_COUNT] = {"k_frame_pack", "k_tx_mod",   "k_channel", "k_sync",
-                                            "k_peak",       "k_rx_demod", "k_deframe"};
+                                            "k_peak",       "k_rx_demod", "k_deframe", "k_sense"};
   return (k >= 0 && k < OFDM_K_COUNT) ? names[k] : "?";
 }
 
@@ -301,6 +316,15 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
   for (DevBuf* b : bufs) b->release();
   h->h_meta.release();
   h->rx.release();
+  {
+    SenseState& ss = h->sense;
+    if (ss.side) (void)hipStreamSynchronize(ss.side);
+    DevBuf* sb[] = {&ss.d_win, &ss.d_tw, &ss.d_msgs, &ss.d_mean, &ss.d_bits, &ss.d_hex, &ss.x_stage};
+    for (DevBuf* b : sb) b->release();
+    if (ss.ev_in) (void)hipEventDestroy(ss.ev_in);
+    if (ss.ev_out) (void)hipEventDestroy(ss.ev_out);
+    if (ss.side) (void)hipStreamDestroy(ss.side);
+  }
   h->prof.destroy();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -594,4 +618,5 @@ extern "C" int ofdm_channel(ofdm_handle* h, ofdm_c32* iq, uint64_t n, const ofdm
   return OFDM_OK;
 }
 
+#include "engine_sense.inc"
 #include "engine_rx.inc"

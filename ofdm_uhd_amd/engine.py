@@ -215,6 +215,66 @@ class Engine(object):
         n = npk.value
         return n, off[:n + 1], ln[:n], ok[:n]
 
+    # -- spectrum sensing ----------------------------------------------------------
+    def _sense_outputs(self, sc, nm, nd):
+        S = sc.fft_size
+        return (np.zeros((max(nm, 1), S), np.float32), np.zeros((max(nd, 1), S), np.float64),
+                np.zeros((max(nd, 1), S), np.uint8), np.zeros((max(nd, 1), S // 4), np.uint8))
+
+    @staticmethod
+    def _sense_pack(msgs, mean, bits, hexs, nm, nd):
+        return {"msgs": msgs[:nm], "mean": mean[:nd], "bits": bits[:nd],
+                "hex": [hexs[d].tobytes().decode("ascii") for d in range(nd)]}
+
+    def sense_count(self, sc, nsamples):
+        nm, nd = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.ofdm_sense_count(C.byref(sc), int(nsamples), C.byref(nm), C.byref(nd)))
+        return nm.value, nd.value
+
+    def sense(self, sc, iq, nsamples=None):
+        """The `sensor` flowgraph + sense_loop of predictive_sense.py over one IQ stream.
+        Returns {"msgs": float32[nmsgs][fft] (bin_statistics_f message bodies, FFT order),
+        "mean": float64[ndec][fft], "bits": uint8[ndec][fft] (both ascending frequency),
+        "hex": [str]} -- one hex carrier map per decision, as hex_conv returns it."""
+        if self.device_ptrs:
+            ptr, n = C.c_void_p(int(iq)), int(nsamples)
+        else:
+            iq = np.ascontiguousarray(iq, np.complex64)
+            ptr, n = (_ptr(iq) if len(iq) else None), len(iq)
+        nm, nd = self.sense_count(sc, n)
+        msgs, mean, bits, hexs = self._sense_outputs(sc, nm, nd)
+        onm, ond = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.ofdm_sense(self._h, C.byref(sc), ptr, n, _ptr(msgs), max(nm, 1), _ptr(mean), _ptr(bits),
+                                         _ptr(hexs), max(nd, 1), C.byref(onm), C.byref(ond)))
+        return self._sense_pack(msgs, mean, bits, hexs, onm.value, ond.value)
+
+    def sense_decide(self, sc, msgs):
+        """sense_loop alone over message bodies [nmsgs][fft_size] (e.g. from a real msg_queue)."""
+        msgs = np.ascontiguousarray(msgs, np.float32)
+        nm = msgs.shape[0]
+        nd = nm // (sc.avg_msgs + sc.skip_msgs)
+        _, mean, bits, hexs = self._sense_outputs(sc, 0, nd)
+        ond = C.c_uint64(0)
+        self._check(self._lib.ofdm_sense_decide(self._h, C.byref(sc), _ptr(msgs), nm, _ptr(mean), _ptr(bits),
+                                                _ptr(hexs), max(nd, 1), C.byref(ond)))
+        r = self._sense_pack(msgs, mean, bits, hexs, nm, ond.value)
+        del r["msgs"]
+        return r
+
+    def set_rx_sense(self, sc):
+        """Fuse the sensor into every following rx()/rx_device() call (None switches it off)."""
+        self._rx_sense_cfg = sc
+        self._check(self._lib.ofdm_set_rx_sense(self._h, C.byref(sc) if sc is not None else None))
+
+    def rx_sense_result(self, nsamples):
+        sc = self._rx_sense_cfg
+        nm, nd = self.sense_count(sc, nsamples)
+        msgs, mean, bits, hexs = self._sense_outputs(sc, nm, nd)
+        onm, ond = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.ofdm_rx_sense_result(self._h, _ptr(msgs), max(nm, 1), _ptr(mean), _ptr(bits), _ptr(hexs),
+                                                   max(nd, 1), C.byref(onm), C.byref(ond)))
+        return self._sense_pack(msgs, mean, bits, hexs, onm.value, ond.value)
+
     # -- taps ---------------------------------------------------------------------
     _TAP_DTYPES = {
         _abi.TAP_TX_PACKETS: np.uint8, _abi.TAP_TX_FREQ: np.complex64, _abi.TAP_RX_CHAN_FILT: np.complex64,

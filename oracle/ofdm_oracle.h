@@ -38,6 +38,14 @@ int orc_rx_packets(const orc_rx_result *r, uint8_t *payload_out, uint64_t cap, u
 void orc_rx_stats(const orc_rx_result *r, ofdm_stats *st);
 void orc_rx_free(orc_rx_result *r);
 
+/* spectrum sensor (predictive_sense.py:72-123,150-268); outputs may be NULL */
+int orc_sense_count(const ofdm_sense_cfg *sc, uint64_t nsamples, uint64_t *nmsgs, uint64_t *ndecisions);
+int orc_sense(const ofdm_sense_cfg *sc, const ofdm_c32 *iq, uint64_t nsamples, float *msgs, double *mean_inorder,
+              uint8_t *bits_inorder, char *hex);
+/* sense_loop's tail alone, from ready-made message bodies (pinned by the recorded run logs) */
+int orc_sense_decide(const ofdm_sense_cfg *sc, const float *msgs, uint64_t nmsgs, double *mean_inorder,
+                     uint8_t *bits_inorder, char *hex);
+
 #ifdef __cplusplus
 }
 #endif

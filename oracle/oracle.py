@@ -57,6 +57,10 @@ def lib():
         L.orc_rx_stats.argtypes = [vp, C.POINTER(_abi.ofdm_stats)]
         L.orc_rx_stats.restype = None
         L.orc_rx_free.argtypes = [vp]
+        SC = C.POINTER(_abi.ofdm_sense_cfg)
+        L.orc_sense_count.argtypes = [SC, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_sense.argtypes = [SC, vp, C.c_uint64, vp, vp, vp, vp]
+        L.orc_sense_decide.argtypes = [SC, vp, C.c_uint64, vp, vp, vp]
         L.orc_rx_free.restype = None
         _LIB = L
     return _LIB
@@ -203,3 +207,42 @@ class RxResult(object):
 
 def rx(cfg, iq, tap_mask=0):
     return RxResult(cfg, iq, tap_mask)
+
+
+def sense_count(sc, nsamples):
+    nm, nd = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().orc_sense_count(C.byref(sc), int(nsamples), C.byref(nm), C.byref(nd))
+    if rc:
+        raise ValueError("orc_sense_count: %d" % rc)
+    return nm.value, nd.value
+
+
+def _sense_out(sc, nm, nd):
+    S = sc.fft_size
+    return (np.zeros((max(nd, 1), S), np.float64), np.zeros((max(nd, 1), S), np.uint8),
+            np.zeros((max(nd, 1), S // 4), np.uint8))
+
+
+def sense(sc, iq):
+    """predictive_sense.py sensor graph + sense_loop: same dict as Engine.sense."""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    nm, nd = sense_count(sc, len(iq))
+    msgs = np.zeros((max(nm, 1), sc.fft_size), np.float32)
+    mean, bits, hexs = _sense_out(sc, nm, nd)
+    rc = lib().orc_sense(C.byref(sc), _ptr(iq), len(iq), _ptr(msgs), _ptr(mean), _ptr(bits), _ptr(hexs))
+    if rc:
+        raise ValueError("orc_sense: %d" % rc)
+    return {"msgs": msgs[:nm], "mean": mean[:nd], "bits": bits[:nd],
+            "hex": [hexs[d].tobytes().decode("ascii") for d in range(nd)]}
+
+
+def sense_decide(sc, msgs):
+    """sense_loop's tail alone on ready-made message bodies [nmsgs][fft_size]."""
+    msgs = np.ascontiguousarray(msgs, np.float32)
+    nm = msgs.shape[0]
+    nd = nm // (sc.avg_msgs + sc.skip_msgs)
+    mean, bits, hexs = _sense_out(sc, nm, nd)
+    rc = lib().orc_sense_decide(C.byref(sc), _ptr(msgs), nm, _ptr(mean), _ptr(bits), _ptr(hexs))
+    if rc:
+        raise ValueError("orc_sense_decide: %d" % rc)
+    return {"mean": mean[:nd], "bits": bits[:nd], "hex": [hexs[d].tobytes().decode("ascii") for d in range(nd)]}
