@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define OFDM_ABI_VERSION 1
+#define OFDM_ABI_VERSION 2
 
 #define OFDM_MAX_FFT 4096
+#define OFDM_MAX_CARRIER_HEX 1024 /* hex digits of a carrier map: OFDM_MAX_FFT / 4 */
 #define OFDM_MAX_TAPS 512
 #define OFDM_MAX_ARITY 256
 #define OFDM_MASK_LEN 4096      /* len(random_mask_tuple), ofdm_packet_utils.py:195 */
@@ -92,6 +93,10 @@ typedef struct ofdm_cfg {
   uint32_t whitener_offset;              /* make_packet whitener_offset, 0..15 (ofdm_packet_utils.py:100) */
 
   uint64_t pad_seed; /* seed of the counter-based generator that replaces the mapper's rand()%arity fill */
+  /* data-carrier map as a hex string, NUL terminated; "" = the mapper's built-in "FE7F"
+   * (transmit_path.py:64).  Used identically by the mapper (container fft_length) and the
+   * frame sink (container occupied_tones); see ofdm_set_carrier_map. */
+  char carrier_map[OFDM_MAX_CARRIER_HEX + 8];
 } ofdm_cfg;
 
 /* Synthetic channel fused into the TX store (replaces the UHD sink/source pair
@@ -131,6 +136,14 @@ const char *ofdm_last_error(const ofdm_handle *h); /* h may be NULL: error of th
 int ofdm_set_stream(ofdm_handle *h, void *hip_stream);
 /* transmit_path.set_tx_amplitude (transmit_path.py:56-62); clamps to [0,1] */
 int ofdm_set_tx_amplitude(ofdm_handle *h, float ampl);
+/* digital_ofdm_mapper_bcv::reset_carrier_map of the reference's patched GNU Radio
+ * (transmit_path.py:64-70; the call is commented out at :67, so the stock behaviour is
+ * never to change it): rebuilds the mapper's and the frame sink's subcarrier tables from a
+ * hex string such as the one hex_conv returns (clipped to occupied_tones/4 digits,
+ * sensing_and_tramsmitting.py:470).  NULL or "" restores "FE7F".  OFDM_E_INVAL when the
+ * string holds a non-hex digit or allocates more carriers than occupied_tones (the
+ * blocks' std::invalid_argument); the previous map then stays in force. */
+int ofdm_set_carrier_map(ofdm_handle *h, const char *hex);
 /* channel applied inside ofdm_tx; NULL disables it */
 int ofdm_set_channel(ofdm_handle *h, const ofdm_chan *chan);
 

@@ -7,12 +7,13 @@ __graft_entry__ as g; g.build()"`` or ``make -C ofdm_uhd_amd/csrc``).
 import ctypes as C
 import os
 
-OFDM_ABI_VERSION = 1
+OFDM_ABI_VERSION = 2
 OFDM_MAX_FFT = 4096
 OFDM_MAX_TAPS = 512
 OFDM_MAX_ARITY = 256
 OFDM_MASK_LEN = 4096
 OFDM_MAX_PKT_LEN = 4096
+OFDM_MAX_CARRIER_HEX = 1024
 
 OFDM_OK = 0
 OFDM_E_INVAL = -1
@@ -60,6 +61,7 @@ class ofdm_cfg(C.Structure):
         ("whitening_mask", C.c_uint8 * OFDM_MASK_LEN),
         ("whitener_offset", C.c_uint32),
         ("pad_seed", C.c_uint64),
+        ("carrier_map", C.c_char * (OFDM_MAX_CARRIER_HEX + 8)),
     ]
 
 
@@ -99,7 +101,7 @@ class ofdm_sense_cfg(C.Structure):
 # every symbol include/ofdm_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "ofdm_abi_version", "ofdm_device_count", "ofdm_create", "ofdm_destroy", "ofdm_last_error",
-    "ofdm_set_stream", "ofdm_set_tx_amplitude", "ofdm_set_channel", "ofdm_framed_len",
+    "ofdm_set_stream", "ofdm_set_tx_amplitude", "ofdm_set_carrier_map", "ofdm_set_channel", "ofdm_framed_len",
     "ofdm_make_packets", "ofdm_tx_frame_count", "ofdm_tx", "ofdm_channel", "ofdm_rx",
     "ofdm_set_taps", "ofdm_tap", "ofdm_prof_enable", "ofdm_prof_reset", "ofdm_prof_get",
     "ofdm_kernel_name", "ofdm_sense_count", "ofdm_sense", "ofdm_sense_decide", "ofdm_set_rx_sense",
@@ -124,6 +126,7 @@ def _declare(lib):
     lib.ofdm_last_error.restype = C.c_char_p
     lib.ofdm_set_stream.argtypes = [H, vp]
     lib.ofdm_set_tx_amplitude.argtypes = [H, C.c_float]
+    lib.ofdm_set_carrier_map.argtypes = [H, C.c_char_p]
     lib.ofdm_set_channel.argtypes = [H, C.POINTER(ofdm_chan)]
     lib.ofdm_framed_len.argtypes = [H, C.c_uint32, u32p]
     lib.ofdm_make_packets.argtypes = [H, u8p, u64p, u32p, C.c_int, u8p, C.c_uint64, u64p]

@@ -92,16 +92,20 @@ def carrier_map(occupied_tones, container, carriers="FE7F"):
     pad = int((container // 4 - len(s)) / 2)  # C integer division (truncates toward zero)
     out = []
     for i, ch in enumerate(s):
+        if ch not in "0123456789abcdefABCDEF":
+            raise ValueError("carrier map holds a non-hex digit: %r" % ch)
         v = int(ch, 16)
         for j in range(4):
             if (v >> (3 - j)) & 1:
                 out.append(4 * (i + pad) + j)
     if len(out) > occupied_tones:
         raise ValueError("subcarriers allocated exceeds size of occupied carriers")
+    if not out or min(out) < 0 or max(out) >= container:
+        raise ValueError("carrier map leaves no usable data carrier inside the container")
     return out
 
 
-def make_cfg(options, pad_for_usrp=False, device_ptrs=False, device_id=0, pad_seed=0x0FD30000):
+def make_cfg(options, pad_for_usrp=False, device_ptrs=False, device_id=0, pad_seed=0x0FD30000, carriers=None):
     """Build the engine configuration from an options object carrying the
     reference's attribute names (modulation, fft_length, occupied_tones, cp_length,
     tx_amplitude ...)."""
@@ -153,6 +157,14 @@ def make_cfg(options, pad_for_usrp=False, device_ptrs=False, device_id=0, pad_se
     ctypes.memmove(cfg.whitening_mask, mask, len(mask))
     cfg.whitener_offset = 0
     cfg.pad_seed = int(pad_seed)
+    if carriers is None:
+        carriers = getattr(options, "carrier_map", None)
+    if carriers:
+        if len(carriers) > _abi.OFDM_MAX_CARRIER_HEX:
+            raise ValueError("carrier map longer than %d hex digits" % _abi.OFDM_MAX_CARRIER_HEX)
+        carrier_map(occ, N, carriers)      # raises ValueError exactly where the blocks' ctors would
+        carrier_map(occ, occ, carriers)
+        cfg.carrier_map = carriers.encode("ascii")
     return cfg
 
 

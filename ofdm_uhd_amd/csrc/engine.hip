@@ -85,30 +85,35 @@ static int ilog2_ceil(unsigned v) {
   return n;
 }
 
-// digital_ofdm_mapper_bcv / digital_ofdm_frame_sink carrier map from the default "FE7F"
-// string (transmit_path.py:64; reset_carrier_map is commented out at :67)
-static int build_carrier_map(int occ, int container, std::vector<int>& map) {
+// digital_ofdm_mapper_bcv / digital_ofdm_frame_sink carrier map from a hex string (default
+// "FE7F", transmit_path.py:64): the string is grown with 'f' on both sides until it covers
+// occ carriers (a last partial nibble split left/right), then centred in the container in
+// units of four carriers; MSB of a digit = lowest carrier of its nibble.
+static int build_carrier_map(int occ, int container, const char* carriers, std::vector<int>& map) {
   std::vector<int> digits;
   if (occ < 16) return OFDM_E_INVAL;
-  int diff = occ - 16, nf = 0;
+  if (!carriers || !carriers[0]) carriers = "FE7F";
+  for (const char* c = carriers; *c; c++) {
+    int v;
+    if (*c >= '0' && *c <= '9') v = *c - '0';
+    else if (*c >= 'a' && *c <= 'f') v = *c - 'a' + 10;
+    else if (*c >= 'A' && *c <= 'F') v = *c - 'A' + 10;
+    else return OFDM_E_INVAL;
+    digits.push_back(v);
+    if (digits.size() > OFDM_MAX_CARRIER_HEX) return OFDM_E_INVAL;
+  }
+  int diff = occ - 4 * (int)digits.size();
   while (diff > 7) {
-    nf++;
+    digits.insert(digits.begin(), 0xF);
+    digits.push_back(0xF);
     diff -= 8;
   }
-  int dl = 0, dr = 0;
   if (diff > 0) {
-    dl = (diff + 1) / 2;
-    dr = diff - dl;
-    digits.push_back((1 << dl) - 1);
+    const int dl = (diff + 1) / 2, dr = diff - dl;
+    digits.insert(digits.begin(), (1 << dl) - 1);
+    digits.push_back(0xF ^ ((1 << dr) - 1));
   }
-  for (int i = 0; i < nf; i++) digits.push_back(0xF);
-  digits.push_back(0xF);
-  digits.push_back(0xE);
-  digits.push_back(0x7);
-  digits.push_back(0xF);
-  for (int i = 0; i < nf; i++) digits.push_back(0xF);
-  if (diff > 0) digits.push_back(0xF ^ ((1 << dr) - 1));
-  int pad = (container / 4 - (int)digits.size()) / 2;
+  const int pad = (container / 4 - (int)digits.size()) / 2;  // C integer division, as the blocks do
   map.clear();
   for (size_t i = 0; i < digits.size(); i++)
     for (int j = 0; j < 4; j++)
@@ -117,7 +122,8 @@ static int build_carrier_map(int occ, int container, std::vector<int>& map) {
         if (idx < 0 || idx >= container) return OFDM_E_INVAL;
         map.push_back(idx);
       }
-  if ((int)map.size() > occ) return OFDM_E_INVAL;
+  if ((int)map.size() > occ) return OFDM_E_INVAL;  // "subcarriers allocated exceeds size of occupied carriers"
+  if (map.empty()) return OFDM_E_INVAL;            // no data carrier at all: nothing could ever be sent
   return OFDM_OK;
 }
 
@@ -194,6 +200,26 @@ extern "C" const char* ofdm_kernel_name(int k) {
   return (k >= 0 && k < OFDM_K_COUNT) ? names[k] : "?";
 }
 
+// (re)build the mapper's bin->carrier table and the frame sink's carrier list
+static int apply_carrier_map(ofdm_handle* h, const char* hex) {
+  const int N = (int)h->cfg.fft_length, occ = (int)h->cfg.occupied_tones;
+  std::vector<int> cmap, smap;
+  if (build_carrier_map(occ, N, hex, cmap) != OFDM_OK)
+    FAIL(h, OFDM_E_INVAL, "carrier map: bad hex digit, or subcarriers allocated exceeds size of occupied carriers (mapper)");
+  if (build_carrier_map(occ, occ, hex, smap) != OFDM_OK)
+    FAIL(h, OFDM_E_INVAL, "carrier map: bad hex digit, or subcarriers allocated exceeds size of occupied carriers (frame sink)");
+  std::vector<int16_t> bin2car(N, (int16_t)-1);
+  for (size_t i = 0; i < cmap.size(); i++) bin2car[cmap[i]] = (int16_t)i;
+  std::vector<int16_t> smap16(smap.begin(), smap.end());
+  // work in flight may still read the old tables
+  if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, upload(h->d_bin2car, bin2car.data(), bin2car.size()));
+  HIPCHK(h, upload(h->d_smap, smap16.data(), smap16.size()));
+  h->nc = (int)cmap.size();
+  h->nmap = (int)smap.size();
+  return OFDM_OK;
+}
+
 static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   h->cfg = *cfg;
   const int N = (int)cfg->fft_length, occ = (int)cfg->occupied_tones, CP = (int)cfg->cp_length;
@@ -222,15 +248,13 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
 
-  std::vector<int> cmap, smap;
-  if (build_carrier_map(occ, N, cmap) != OFDM_OK) FAIL(h, OFDM_E_INVAL, "cannot build the mapper's subcarrier map");
-  if (build_carrier_map(occ, occ, smap) != OFDM_OK) FAIL(h, OFDM_E_INVAL, "cannot build the frame sink's subcarrier map");
-  h->nc = (int)cmap.size();
-  h->nmap = (int)smap.size();
+  h->cfg.carrier_map[OFDM_MAX_CARRIER_HEX + 7] = 0;
+  {
+    int rc = apply_carrier_map(h, h->cfg.carrier_map);
+    if (rc != OFDM_OK) return rc;
+  }
 
   // tables
-  std::vector<int16_t> bin2car(N, (int16_t)-1);
-  for (int i = 0; i < h->nc; i++) bin2car[cmap[i]] = (int16_t)i;
   std::vector<c32> pre(N), tw(N);
   for (int i = 0; i < N; i++) pre[i] = c32{0.f, 0.f};
   for (int i = 0; i < occ; i++) {
@@ -256,12 +280,9 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
     float di = cfg->known_symbol[i].im - cfg->known_symbol[i + 2].im;
     kd[i] = dr * dr + di * di;
   }
-  std::vector<int16_t> smap16(smap.begin(), smap.end());
-
   HIPCHK(h, upload(h->d_const, reinterpret_cast<const c32*>(cfg->constellation), cfg->arity));
   HIPCHK(h, upload(h->d_preamble, pre.data(), pre.size()));
   HIPCHK(h, upload(h->d_tw, tw.data(), tw.size()));
-  HIPCHK(h, upload(h->d_bin2car, bin2car.data(), bin2car.size()));
   HIPCHK(h, upload(h->d_mask, cfg->whitening_mask, (size_t)OFDM_MASK_LEN));
   HIPCHK(h, upload(h->d_crc, crc, (size_t)256));
   {
@@ -277,7 +298,6 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   }
   HIPCHK(h, upload(h->d_taps, taps.data(), taps.size()));
   HIPCHK(h, upload(h->d_ks, reinterpret_cast<const c32*>(cfg->known_symbol), (size_t)occ));
-  HIPCHK(h, upload(h->d_smap, smap16.data(), smap16.size()));
   HIPCHK(h, upload(h->d_kd, kd.data(), kd.size()));
   return OFDM_OK;
 }
@@ -333,6 +353,17 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
 extern "C" int ofdm_set_stream(ofdm_handle* h, void* s) {
   if (!h) return OFDM_E_INVAL;
   h->stream = s ? (hipStream_t)s : h->own_stream;
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_set_carrier_map(ofdm_handle* h, const char* hex) {
+  if (!h) return OFDM_E_INVAL;
+  if (hex && strlen(hex) > OFDM_MAX_CARRIER_HEX) FAIL(h, OFDM_E_INVAL, "carrier map longer than 1024 hex digits");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int rc = apply_carrier_map(h, hex ? hex : "");
+  if (rc != OFDM_OK) return rc;
+  memset(h->cfg.carrier_map, 0, sizeof(h->cfg.carrier_map));
+  if (hex) strcpy(h->cfg.carrier_map, hex);
   return OFDM_OK;
 }
 

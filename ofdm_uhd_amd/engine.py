@@ -85,6 +85,12 @@ class Engine(object):
     def set_tx_amplitude(self, ampl):
         self._check(self._lib.ofdm_set_tx_amplitude(self._h, float(ampl)))
 
+    def set_carrier_map(self, carriers="FE7F"):
+        """reset_carrier_map of the reference's patched mapper (transmit_path.py:67): swap the data
+        carrier map of BOTH directions of this engine, e.g. to hex_conv's output clipped to
+        occupied_tones/4 digits (sensing_and_tramsmitting.py:470)."""
+        self._check(self._lib.ofdm_set_carrier_map(self._h, (carriers or "").encode("ascii")))
+
     def set_channel(self, sigma=0.0, cfo=0.0, seed=0xC0FFEE, stream_id=0, lead=0, tail=0, enable=True):
         if not enable:
             self._check(self._lib.ofdm_set_channel(self._h, None))

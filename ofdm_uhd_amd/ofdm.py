@@ -85,6 +85,13 @@ class ofdm_mod(object):
             raise ValueError("len(payload) must be in [0, %d]" % (len(ofdm_packet_utils.random_mask_tuple),))
         self._pending.append(payload)
 
+    def reset_carrier_map(self, carrier_map_new):
+        """digital_ofdm_mapper_bcv.reset_carrier_map of the reference's patched GNU Radio
+        (the call transmit_path.py:67 has commented out): packets queued so far go out on the old
+        map, later ones on the new one."""
+        self.flush()
+        self._engine.set_carrier_map(carrier_map_new)
+
     def flush(self):
         """Modulate everything queued so far; returns the samples (also written to the sink)."""
         if not self._pending:
@@ -184,6 +191,11 @@ class ofdm_demod(object):
 
     def run(self, source):
         return self.work(source.read_all())
+
+    def reset_carrier_map(self, carrier_map_new):
+        """The frame sink's side of reset_carrier_map: streams demodulated from now on are
+        de-mapped with the new data-carrier set."""
+        self._engine.set_carrier_map(carrier_map_new)
 
     def last_stats(self):
         return dict(self._engine.last_stats)

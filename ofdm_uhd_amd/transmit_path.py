@@ -5,7 +5,10 @@ from . import ofdm
 
 
 class transmit_path(object):
-    def __init__(self, options, device_id=0):
+    def __init__(self, options, device_id=0, apply_carrier_map=False):
+        """``apply_carrier_map=True`` restores the line the reference has commented out
+        (transmit_path.py:67): send_pkt's carrier_map_new is then really handed to the mapper."""
+        self._apply_carrier_map = bool(apply_carrier_map)
         options = copy.copy(options)    # make a copy so we can destructively modify
 
         self._verbose = getattr(options, "verbose", False)
@@ -35,6 +38,8 @@ class transmit_path(object):
         # the reference remembers the requested map but never applies it
         # (reset_carrier_map is commented out, transmit_path.py:66-68)
         if carrier_map_new != self.carrier_map_old:
+            if self._apply_carrier_map:
+                self.ofdm_tx.reset_carrier_map(carrier_map_new)
             self.carrier_map_old = carrier_map_new
         return self.ofdm_tx.send_pkt(payload, eof)
 

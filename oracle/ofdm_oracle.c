@@ -242,14 +242,20 @@ int orc_unmake_packet(const ofdm_cfg *cfg, const uint8_t *msg, uint32_t len, uin
 /* subcarrier map  (digital_ofdm_mapper_bcv ctor at ofdm.py:106 with
  * container = fft_length; digital_ofdm_frame_sink ctor at ofdm.py:240 with
  * container = occupied_tones).  Default carrier string "FE7F"
- * (transmit_path.py:64 default, reset_carrier_map commented out :67).        */
+ * (transmit_path.py:64 default, reset_carrier_map commented out :67); any other
+ * hex string (cfg->carrier_map) goes through the same growth / centring rule.  */
 /* ------------------------------------------------------------------------ */
-int orc_carrier_map(int occ, int container, int *map, int cap) {
+int orc_carrier_map(int occ, int container, const char *carriers, int *map, int cap) {
   /* hex digit values, MSB = lowest carrier of the nibble */
-  int digits[OFDM_MAX_FFT / 4 + 8];
+  int digits[OFDM_MAX_CARRIER_HEX + OFDM_MAX_FFT / 4 + 8];
   int nd = 0;
   if (occ < 16 || occ > OFDM_MAX_FFT || container > OFDM_MAX_FFT) return OFDM_E_INVAL;
-  int diff = occ - 16;
+  if (!carriers || !carriers[0]) carriers = "FE7F";
+  size_t len = strlen(carriers);
+  if (len > OFDM_MAX_CARRIER_HEX) return OFDM_E_INVAL;
+  /* the ctor's loop: while (diff > 7) { carriers = "f" + carriers + "f"; diff -= 8; } then a
+   * final partial nibble split ceil(diff/2) left, the rest right */
+  int diff = occ - 4 * (int)len;
   int nf = 0;
   while (diff > 7) {
     nf++;
@@ -263,10 +269,15 @@ int orc_carrier_map(int occ, int container, int *map, int cap) {
     digits[nd++] = (1 << dl) - 1;
   }
   for (int i = 0; i < nf; i++) digits[nd++] = 0xF;
-  digits[nd++] = 0xF;
-  digits[nd++] = 0xE;
-  digits[nd++] = 0x7;
-  digits[nd++] = 0xF;
+  for (size_t i = 0; i < len; i++) {
+    char c = carriers[i];
+    int v;
+    if (c >= '0' && c <= '9') v = c - '0';
+    else if (c >= 'a' && c <= 'f') v = c - 'a' + 10;
+    else if (c >= 'A' && c <= 'F') v = c - 'A' + 10;
+    else return OFDM_E_INVAL;
+    digits[nd++] = v;
+  }
   for (int i = 0; i < nf; i++) digits[nd++] = 0xF;
   if (have_extra) digits[nd++] = 0xF ^ ((1 << dr) - 1);
   int pad = (container / 4 - nd) / 2; /* C integer division, as the C++ does */
@@ -280,6 +291,7 @@ int orc_carrier_map(int occ, int container, int *map, int cap) {
         map[n++] = idx;
       }
   if (n > occ) return OFDM_E_INVAL; /* "subcarriers allocated exceeds size of occupied carriers" */
+  if (n == 0) return OFDM_E_INVAL;
   return n;
 }
 
@@ -382,7 +394,7 @@ int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload
   int nbits = orc_nbits(cfg);
   if (occ > N) return OFDM_E_INVAL; /* mapper ctor: occupied_carriers > fft_length */
   int *map = (int *)malloc(sizeof(int) * (size_t)occ);
-  int nc = orc_carrier_map(occ, N, map, occ);
+  int nc = orc_carrier_map(occ, N, cfg->carrier_map, map, occ);
   if (nc < 0) {
     free(map);
     return nc;
@@ -849,7 +861,7 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   sk->nbits = orc_nbits(cfg);
   sk->occ = occ;
   memcpy(sk->pos, cfg->constellation, sizeof(ofdm_c32) * cfg->arity);
-  sk->nmap = orc_carrier_map(occ, occ, sk->map, OFDM_MAX_FFT);
+  sk->nmap = orc_carrier_map(occ, occ, cfg->carrier_map, sk->map, OFDM_MAX_FFT);
   sk->phase_gain = cfg->phase_gain;
   sk->freq_gain = cfg->freq_gain;
   sk->eq_gain = cfg->eq_gain;

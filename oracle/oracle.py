@@ -36,7 +36,7 @@ def lib():
         L.orc_make_packet.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
         L.orc_unmake_packet.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, C.c_uint32, vp, C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_int)]
-        L.orc_carrier_map.argtypes = [C.c_int, C.c_int, vp, C.c_int]
+        L.orc_carrier_map.argtypes = [C.c_int, C.c_int, C.c_char_p, vp, C.c_int]
         L.orc_tx_data_symbols.restype = C.c_uint32
         L.orc_tx_data_symbols.argtypes = [C.POINTER(_abi.ofdm_cfg), C.c_uint32, C.c_int]
         L.orc_pad_symbol.restype = C.c_uint32
@@ -98,9 +98,9 @@ def unmake_packet(cfg, msg):
     return bool(ok.value), out[:n.value].tobytes()
 
 
-def carrier_map(occ, container):
+def carrier_map(occ, container, carriers="FE7F"):
     m = np.zeros(_abi.OFDM_MAX_FFT, np.int32)
-    n = lib().orc_carrier_map(occ, container, _ptr(m), len(m))
+    n = lib().orc_carrier_map(occ, container, carriers.encode("ascii"), _ptr(m), len(m))
     if n < 0:
         raise ValueError("orc_carrier_map rc=%d" % n)
     return m[:n].copy()
@@ -121,7 +121,7 @@ def tx(cfg, payloads, lead=0, tail=0, want_taps=False):
     L = lib()
     blob, offs, lens = pack_payloads(payloads)
     N, CP = cfg.fft_length, cfg.cp_length
-    ncar = len(carrier_map(cfg.occupied_tones, N))
+    ncar = len(carrier_map(cfg.occupied_tones, N, cfg.carrier_map.decode('ascii') or 'FE7F'))
     nsym = 0
     flens = []
     for ln in lens:

@@ -27,18 +27,27 @@ def test_library_loads_and_exports_everything():
     assert lib.ofdm_kernel_name(_abi.K_SYNC) == b"k_sync"
 
 
-def test_struct_layout_matches_header():
-    # sizes implied by include/ofdm_hip.h (natural alignment, 8-byte pad_seed at the end)
-    assert ctypes.sizeof(_abi.ofdm_c32) == 8
-    assert ctypes.sizeof(_abi.ofdm_chan) == 40
-    assert ctypes.sizeof(_abi.ofdm_stats) == 72
-    cfg = _abi.ofdm_cfg
-    assert cfg.constellation.offset == 28
-    assert cfg.known_symbol.offset == 28 + 8 * 256
-    assert cfg.tx_amplitude.offset == 28 + 8 * 256 + 8 * 4096
-    assert cfg.taps.offset == cfg.ntaps.offset + 4
-    assert cfg.whitening_mask.offset == cfg.taps.offset + 4 * 512
-    assert ctypes.sizeof(cfg) == 41040
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof as the C compiler sees include/ofdm_hip.h == the ctypes mirror."""
+    import subprocess
+    structs = {"ofdm_cfg": _abi.ofdm_cfg, "ofdm_chan": _abi.ofdm_chan, "ofdm_stats": _abi.ofdm_stats,
+               "ofdm_sense_cfg": _abi.ofdm_sense_cfg, "ofdm_c32": _abi.ofdm_c32}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ofdm_hip.h"', 'int main(void){']
+    for name, st in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for f, _ in st._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src)])
+    got = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+    for name, st in structs.items():
+        assert int(got[name]) == ctypes.sizeof(st), name
+        for f, _ in st._fields_:
+            assert int(got["%s.%s" % (name, f)]) == getattr(st, f).offset, (name, f)
+    assert ctypes.sizeof(_abi.ofdm_cfg) == 41040 + 1032
 
 
 def test_create_rejects_bad_abi_or_config_without_a_gpu():

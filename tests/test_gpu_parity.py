@@ -42,6 +42,12 @@ def test_tx_parity(orc, mod, N, occ, CP, plen, npkt, snr, cfo):
     cfg = make_cfg(mod, N, occ, CP)
     eng = _engine(cfg)
     pay = make_payloads(npkt, plen)
+    _check_tx(orc, cfg, eng, pay)
+    eng.close()
+
+
+def _check_tx(orc, cfg, eng, pay):
+    N, CP = cfg.fft_length, cfg.cp_length
     assert eng.make_packets(pay) == [orc.make_packet(cfg, p) for p in pay]      # bytes: bit-exact
     eng.set_taps(_abi.TAP_TX_FREQ)
     iq_g = eng.tx(pay)
@@ -50,7 +56,7 @@ def test_tx_parity(orc, mod, N, occ, CP, plen, npkt, snr, cfo):
     assert len(iq_g) == len(iq_o)
     assert np.abs(iq_g - iq_o).max() < 1e-5                                      # |IQ| error bound of the north star
     assert eng.last_stats["symbols"] * (N + CP) == len(iq_g)
-    eng.close()
+    return freq_o
 
 
 @pytest.mark.parametrize("mod,N,occ,CP,plen,npkt,snr,cfo", CASES)
@@ -59,6 +65,16 @@ def test_rx_parity(orc, mod, N, occ, CP, plen, npkt, snr, cfo):
     eng = _engine(cfg)
     pay = make_payloads(npkt, plen)
     x = loopback_stream(orc, cfg, pay, snr_db=snr, cfo_bins=cfo)                # ONE input for both receivers
+    pk = _check_rx(orc, cfg, eng, x)
+    # every packet whose preamble was derotated with a settled frequency estimate is recovered
+    good = [p for ok, p in pk if ok]
+    assert all(p in pay for p in good)
+    if abs(cfo) < 0.1 and mod != "qam256":
+        assert good == pay
+    eng.close()
+
+
+def _check_rx(orc, cfg, eng, x):
     mask = 0
     for t in RX_TAPS:
         mask |= 1 << t
@@ -84,12 +100,60 @@ def test_rx_parity(orc, mod, N, occ, CP, plen, npkt, snr, cfo):
         assert a.shape == b.shape
         if a.size:
             assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(a))), tap
-    # every packet whose preamble was derotated with a settled frequency estimate is recovered
-    good = [p for ok, p in pk if ok]
-    assert all(p in pay for p in good)
-    if abs(cfo) < 0.1 and mod != "qam256":
-        assert good == pay
+    return pk
+
+
+def _sensed_maps():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sense_blocks.json")) as f:
+        return [b["carrier_map"] for b in json.load(f)["blocks"]]
+
+
+@pytest.mark.parametrize("which", [0, 17, 36])
+def test_sensed_carrier_map_parity(orc, which):
+    """a carrier map the reference's sensor recorded (clipped to occ/4 digits as
+    sensing_and_tramsmitting.py:470 does) drives mapper and frame sink; every stage still
+    matches the oracle and the packets survive the loopback."""
+    carriers = _sensed_maps()[which][:50]
+    cfg = make_cfg("qpsk", 512, 200, 128, carriers=carriers)
+    eng = _engine(cfg)
+    pay = make_payloads(5, 700, seed=which)
+    freq = _check_tx(orc, cfg, eng, pay)
+    data = freq.reshape(-1, 512)[1]                                             # first data symbol of packet 0
+    used = np.flatnonzero(np.abs(data) > 0)
+    assert used.tolist() == orc.carrier_map(200, 512, carriers).tolist()
+    assert used.tolist() == config.carrier_map(200, 512, carriers)
+    x = loopback_stream(orc, cfg, pay, snr_db=30.0)
+    pk = _check_rx(orc, cfg, eng, x)
+    assert [p for ok, p in pk if ok] == pay
     eng.close()
+
+
+def test_set_carrier_map_live(orc):
+    """ofdm_set_carrier_map == reset_carrier_map on a live engine: same result as creating it so."""
+    carriers = _sensed_maps()[5][:50]
+    cfg0 = make_cfg("qpsk", 512, 200, 128)
+    cfg1 = make_cfg("qpsk", 512, 200, 128, carriers=carriers)
+    eng = _engine(cfg0)
+    pay = make_payloads(4, 400, seed=3)
+    a0 = eng.tx(pay)
+    eng.set_carrier_map(carriers)
+    a1 = eng.tx(pay)
+    ref = _engine(cfg1)
+    assert np.array_equal(a1, ref.tx(pay)) and not np.array_equal(a1[:len(a0)], a0[:len(a1)])
+    x = loopback_stream(orc, cfg1, pay)
+    assert [p for ok, p in eng.rx(x) if ok] == pay == [p for ok, p in ref.rx(x) if ok]
+    # an illegal map is refused and the old one stays in force
+    with pytest.raises(ValueError):
+        eng.set_carrier_map("F" * 64)               # 256 carriers > 200 occupied
+    with pytest.raises(ValueError):
+        eng.set_carrier_map("FE7G")
+    assert np.array_equal(eng.tx(pay), a1)
+    eng.set_carrier_map("")                         # back to the built-in FE7F
+    assert np.array_equal(eng.tx(pay), a0)
+    eng.close()
+    ref.close()
 
 
 def test_channel_parity(orc):
