@@ -39,7 +39,8 @@ CONFIGS = {
     "c3": dict(N=2048, occ=1200, CP=512, mod="qam16", size=4091, packets=16384, snr=40.0,
                name="N_fft=2048, occ=1200, 16-QAM, CP=512 (BASELINE configs[2])"),
     "c5": dict(N=4096, occ=2400, CP=1024, mod="qam64", size=4091, packets=16384, snr=45.0,
-               name="N_fft=4096, occ=2400, 64-QAM, CP=1024, no sensing tap (BASELINE configs[4] sizing)"),
+               name="N_fft=4096, occ=2400, 64-QAM, CP=1024, predictive_sense FFT fused into RX (BASELINE configs[4])",
+               sense=True),
 }
 
 
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="payload bytes (default: per config)")
     ap.add_argument("--snr", type=float, default=None)
     ap.add_argument("--cpu-packets", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
+    ap.add_argument("--sense", default="auto", choices=("auto", "on", "off"),
+                    help="fuse the predictive_sense.py spectrum sensor into every RX call (auto: on for c5)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="BASELINE.json config to run (default c2 = configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
@@ -136,14 +139,39 @@ def main():
     d_out = torch.empty(P * size + 4096, dtype=torch.uint8, device=dev)
     max_pkts = P + 1024
 
+    # BASELINE config 5: the spectrum sensor of predictive_sense.py rides on the receiver's IQ buffer.  FFT size =
+    # the OFDM FFT size; tune / dwell as sensor.__init__ derives them (1 ms / 10 ms at 6.25 MS/s, in FFT frames);
+    # 10 messages averaged + 1 consumed per decision, threshold 1e-4.
+    sense_on = cfgd.get("sense", False) if args.sense == "auto" else args.sense == "on"
+    sc = None
+    sense_tot = {"messages": 0, "decisions": 0}
+    last_hex = [None]
+    if sense_on:
+        sc = config.make_sense_cfg(N, max(0, int(round(1e-3 * 6.25e6 / N))), max(1, int(round(10e-3 * 6.25e6 / N))),
+                                   10, 1, 0.00010)
+        eng.set_rx_sense(sc)
+
     def step():
         n = eng.tx_device(d_blob.data_ptr(), offs, lens, d_iq.data_ptr(), nsamp)
         tx_stats = dict(eng.last_stats)
         npk, off, ln, ok = eng.rx_device(d_iq.data_ptr(), n, d_out.data_ptr(), d_out.numel(), max_pkts)
-        return tx_stats, dict(eng.last_stats), npk, off, ln, ok
+        rx_stats = dict(eng.last_stats)
+        if sense_on:
+            if world > 1:
+                # cooperative sensing: every GPU decides on the max over all antennas (one small all_reduce)
+                parallel.allreduce_sensed(eng.sense_device_msgs(), device=dev)
+                torch.cuda.synchronize()
+                eng.sense_redecide()
+            res = eng.rx_sense_result(n, want_msgs=False, want_mean=False)
+            nm, nd = eng.sense_count(sc, n)
+            sense_tot["messages"] += nm
+            sense_tot["decisions"] += len(res["hex"])
+            last_hex[0] = res["hex"][-1] if res["hex"] else None
+        return tx_stats, rx_stats, npk, off, ln, ok
 
     for _ in range(args.warmup):
         step()
+    sense_tot["messages"] = sense_tot["decisions"] = 0
     eng.prof_enable(True)
     eng.prof_reset()
     parallel.barrier()
@@ -218,6 +246,18 @@ def main():
                          "path_frac": sym_per_s / world * path_bytes / 1e9 / HBM_PEAK_GBPS},
             "kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
         }
+        if sense_on:
+            sms, sl = prof.get("k_sense", (0.0, 0))
+            # k_sense reads every IQ sample of the accrued vectors once: 8 B/sample
+            used = (sense_tot["messages"] // max(args.steps, 1)) * sc.dwell_delay * sc.fft_size * 8.0
+            out["sensing"] = {"fft_size": sc.fft_size, "tune_delay": sc.tune_delay, "dwell_delay": sc.dwell_delay,
+                              "messages_per_step": sense_tot["messages"] // max(args.steps, 1),
+                              "decisions_per_step": sense_tot["decisions"] // max(args.steps, 1),
+                              "last_carrier_map_head": (last_hex[0] or "")[:64],
+                              "k_sense_avg_ms": sms / max(sl, 1),
+                              "k_sense_GBps": used / (sms / max(sl, 1) * 1e-3) / 1e9 if sms > 0 else None,
+                              "overlapped_with": "k_sync (second HIP stream)",
+                              "fusion": "max over ranks (all_reduce)" if world > 1 else "single antenna"}
         if args.cpu_packets > 0:
             cfg_host = config.make_cfg(opt)
             out["cpu_baseline"] = cpu_baseline(cfg_host, sigma, lead, tail, size, args.cpu_packets)

@@ -225,6 +225,13 @@ int ofdm_set_rx_sense(ofdm_handle *h, const ofdm_sense_cfg *sc);
 int ofdm_rx_sense_result(ofdm_handle *h, float *msgs, uint64_t msgs_cap, double *mean_inorder,
                          uint8_t *bits_inorder, char *hex, uint64_t dec_cap, uint64_t *nmsgs,
                          uint64_t *ndecisions);
+/* cooperative sensing across GPUs (BASELINE config 5): the DEVICE address of the message
+ * bodies of the last run, float32[nmsgs][fft_size], so that the caller can max-reduce them
+ * in place over RCCL (ncclMax; powers are >= 0) ... */
+int ofdm_sense_device_msgs(ofdm_handle *h, void **d_msgs, uint64_t *nmsgs, uint32_t *fft_size);
+/* ... and re-take the decisions (mean / bits / hex) from the reduced bodies; read them with
+ * ofdm_rx_sense_result.  Both calls order themselves after the sensing kernels. */
+int ofdm_sense_redecide(ofdm_handle *h, const ofdm_sense_cfg *sc);
 
 /* --- debug taps: the reference's --log probe points (ofdm.py:123-131,253-254;
  *     ofdm_receiver.py~:144-152).  Enable before the call, read after.  Output

@@ -105,7 +105,7 @@ EXPORTS = (
     "ofdm_make_packets", "ofdm_tx_frame_count", "ofdm_tx", "ofdm_channel", "ofdm_rx",
     "ofdm_set_taps", "ofdm_tap", "ofdm_prof_enable", "ofdm_prof_reset", "ofdm_prof_get",
     "ofdm_kernel_name", "ofdm_sense_count", "ofdm_sense", "ofdm_sense_decide", "ofdm_set_rx_sense",
-    "ofdm_rx_sense_result",
+    "ofdm_rx_sense_result", "ofdm_sense_device_msgs", "ofdm_sense_redecide",
 )
 
 _LIB = None
@@ -148,6 +148,8 @@ def _declare(lib):
     lib.ofdm_sense_decide.argtypes = [H, SC, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p]
     lib.ofdm_set_rx_sense.argtypes = [H, SC]
     lib.ofdm_rx_sense_result.argtypes = [H, vp, C.c_uint64, vp, vp, vp, C.c_uint64, u64p, u64p]
+    lib.ofdm_sense_device_msgs.argtypes = [H, C.POINTER(C.c_void_p), u64p, u32p]
+    lib.ofdm_sense_redecide.argtypes = [H, SC]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("ofdm_abi_version", "ofdm_device_count"):

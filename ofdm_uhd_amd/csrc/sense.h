@@ -26,6 +26,7 @@ struct SenseParams {
   float* msgs;         // [nmsgs][NS], zero-initialised
   uint32_t tune_delay, dwell_delay;
   uint32_t nsplit;     // workgroups per message
+  uint64_t msg0;       // first message of this launch (grid.y is limited to 65535)
 };
 
 constexpr int sense_threads(int ns) { return ns / 8 < 256 ? 256 : ns / 8; }
@@ -40,7 +41,7 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
   c32* lds = reinterpret_cast<c32*>(smem_raw);
   const int tid = threadIdx.x;
   const int g = tid / TPT, t = tid % TPT;
-  const uint64_t msg = blockIdx.y;
+  const uint64_t msg = p.msg0 + blockIdx.y;
   const uint64_t period = (uint64_t)p.tune_delay + p.dwell_delay;
   const uint64_t v0 = msg * period + p.tune_delay;  // first accrued vector of this message
 
@@ -54,15 +55,27 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
   const uint32_t stride = p.nsplit * G;
   // every group of the workgroup runs the same number of rounds (barriers inside fft_run)
   const uint32_t rounds = (p.dwell_delay + stride - 1) / stride;
+  // software pipeline: the loads of round r+1 are in flight while round r is transformed
+  c32 nx[8];
+  {
+    const uint32_t f = blockIdx.x * G + g;
+    const bool live = f < p.dwell_delay;
+    const c32* src = p.x + (v0 + (live ? f : 0)) * (uint64_t)NS;
+#pragma unroll
+    for (int m = 0; m < 8; m++) nx[m] = live ? src[t + m * TPT] : mk(0.f, 0.f);
+  }
   for (uint32_t r = 0; r < rounds; r++) {
     const uint32_t f = r * stride + blockIdx.x * G + g;
     const bool live = f < p.dwell_delay;
     c32 e[8];
-    const c32* src = p.x + (v0 + (live ? f : 0)) * (uint64_t)NS;
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      c32 s = live ? src[t + m * TPT] : mk(0.f, 0.f);
-      e[m] = mk(s.re * w[m], s.im * w[m]);  // fft_vcc: in[i] * window[i]
+    for (int m = 0; m < 8; m++) e[m] = mk(nx[m].re * w[m], nx[m].im * w[m]);  // fft_vcc: in[i] * window[i]
+    {
+      const uint32_t fn = f + stride;
+      const bool ln = (r + 1 < rounds) && fn < p.dwell_delay;
+      const c32* src = p.x + (v0 + (ln ? fn : 0)) * (uint64_t)NS;
+#pragma unroll
+      for (int m = 0; m < 8; m++) nx[m] = ln ? src[t + m * TPT] : mk(0.f, 0.f);
     }
     fft_run<NS, false>(e, t, my, p.tw, [] { __syncthreads(); });
 #pragma unroll

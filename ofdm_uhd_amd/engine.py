@@ -272,14 +272,34 @@ class Engine(object):
         self._rx_sense_cfg = sc
         self._check(self._lib.ofdm_set_rx_sense(self._h, C.byref(sc) if sc is not None else None))
 
-    def rx_sense_result(self, nsamples):
+    def rx_sense_result(self, nsamples, want_msgs=True, want_mean=True):
+        """Outcome of the sensing run fused into the last rx()/rx_device() call.  The message
+        bodies and the means are large for long streams: leave them on the device with
+        want_msgs/want_mean=False when only the decisions are needed."""
         sc = self._rx_sense_cfg
         nm, nd = self.sense_count(sc, nsamples)
-        msgs, mean, bits, hexs = self._sense_outputs(sc, nm, nd)
+        msgs, mean, bits, hexs = self._sense_outputs(sc, nm if want_msgs else 0, nd)
         onm, ond = C.c_uint64(0), C.c_uint64(0)
-        self._check(self._lib.ofdm_rx_sense_result(self._h, _ptr(msgs), max(nm, 1), _ptr(mean), _ptr(bits), _ptr(hexs),
+        self._check(self._lib.ofdm_rx_sense_result(self._h, _ptr(msgs) if want_msgs else None, max(nm, 1),
+                                                   _ptr(mean) if want_mean else None, _ptr(bits), _ptr(hexs),
                                                    max(nd, 1), C.byref(onm), C.byref(ond)))
-        return self._sense_pack(msgs, mean, bits, hexs, onm.value, ond.value)
+        r = self._sense_pack(msgs, mean, bits, hexs, onm.value if want_msgs else 0, ond.value)
+        if not want_msgs:
+            del r["msgs"]
+        if not want_mean:
+            del r["mean"]
+        return r
+
+    def sense_device_msgs(self):
+        """(device pointer, nmsgs, fft_size) of the last run's message bodies, for an in-place
+        cross-GPU max-reduce (parallel.allreduce_sensed); follow with sense_redecide()."""
+        p, nm, S = C.c_void_p(None), C.c_uint64(0), C.c_uint32(0)
+        self._check(self._lib.ofdm_sense_device_msgs(self._h, C.byref(p), C.byref(nm), C.byref(S)))
+        return (p.value or 0), nm.value, S.value
+
+    def sense_redecide(self, sc=None):
+        sc = self._rx_sense_cfg if sc is None else sc
+        self._check(self._lib.ofdm_sense_redecide(self._h, C.byref(sc)))
 
     # -- taps ---------------------------------------------------------------------
     _TAP_DTYPES = {

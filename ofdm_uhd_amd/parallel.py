@@ -59,3 +59,29 @@ def reduce_max(value, device=None):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class _DeviceF32(object):
+    """Zero-copy view of a raw device buffer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def allreduce_sensed(msgs, device=None):
+    """Cooperative sensing (BASELINE config 5): element-wise MAX of the sensed power
+    spectra over all ranks, in place -- every GPU then decides on what ANY antenna heard.
+    ``msgs`` is a torch tensor (CPU with gloo, device with RCCL) or an (engine device pointer,
+    nmsgs, fft_size) triple from Engine.sense_device_msgs().  A few KB to a few MB per dwell: one
+    all_reduce, latency-bound over xGMI."""
+    import torch
+    import torch.distributed as dist
+    if isinstance(msgs, tuple):
+        ptr, nm, S = msgs
+        if not ptr or not nm:
+            return None
+        msgs = torch.as_tensor(_DeviceF32(ptr, (nm, S)), device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(msgs, op=dist.ReduceOp.MAX)
+    return msgs
