@@ -80,21 +80,35 @@ struct SyncParams {
 __host__ __device__ inline int sync_lp(int i) { return i + (i >> 3); }
 
 struct SyncLds {
-  size_t xs, ys, ms, me, ue, misc, total;
+  size_t xs, ys, mh, mt, me, ue, misc, total;
 };
+// LDS diet: between the filter (B2) and the next tile's x store, everything of `xs` beyond the HX history
+// entries is dead.  The tile's M values (mt), and -- rare path -- the exact M (me) live there; the exact
+// u (ue) overlays mt, which is dead by then because the CP newest M values are saved to the small
+// persistent history mh right after the moving average.  At C2 this brings a workgroup from 72 KB to
+// 46 KB = three workgroups per CU.  When CP is too large for me to fit behind mt it gets its own region.
 __host__ __device__ inline SyncLds sync_lds_layout(int HX, int HY, int HM, int CP) {
   SyncLds l;
   size_t o = 0;
   l.xs = o;
-  o += (size_t)(sync_lp(HX + SYNC_TILE) + 2) * sizeof(c32);
+  const size_t xs_bytes = (size_t)(sync_lp(HX + SYNC_TILE) + 2) * sizeof(c32);
+  o += xs_bytes;
   l.ys = o;
   o += (size_t)(sync_lp(HY + SYNC_TILE) + 2) * sizeof(c32);
-  l.ms = o;
-  o += ((size_t)(sync_lp(HM + SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
-  l.me = o;  // exact M over [amin-CP+1, bmax]
-  o += ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
-  l.ue = o;  // exact u over [amin, bmax]
-  o += (size_t)(SYNC_TILE + 8) * sizeof(float);
+  l.mh = o;  // M history: the CP values before the tile
+  o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  // scratch inside xs, 16-byte aligned, after the x history
+  size_t so = ((size_t)(sync_lp(HX) + 1) * sizeof(c32) + 15) & ~(size_t)15;
+  l.mt = so;  // M of the tile; later: exact u over [amin, bmax] (needs SYNC_TILE + 8 floats)
+  l.ue = so;
+  so += ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  const size_t me_bytes = ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
+  if (so + me_bytes <= xs_bytes) {
+    l.me = so;  // exact M over [amin-CP+1, bmax]
+  } else {
+    l.me = o;
+    o += me_bytes;
+  }
   l.misc = o;
   o += 1024;
   l.total = o;
@@ -343,8 +357,11 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 #define STAMP(i) do { } while (0)
 #endif
 
+#ifndef SYNC_PREFETCH
+#define SYNC_PREFETCH 1
+#endif
 template <int U>
-__global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
+__global__ void __launch_bounds__(SYNC_THREADS, 3) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -355,7 +372,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   const SyncLds L = sync_lds_layout(p.HX, p.HY, p.HM, p.CP);
   c32* xs = reinterpret_cast<c32*>(smem + L.xs);
   c32* ys = reinterpret_cast<c32*>(smem + L.ys);
-  float* ms = reinterpret_cast<float*>(smem + L.ms);
+  float* mh = reinterpret_cast<float*>(smem + L.mh);
+  float* mt = reinterpret_cast<float*>(smem + L.mt);
   float* me = reinterpret_cast<float*>(smem + L.me);
   float* ue = reinterpret_cast<float*>(smem + L.ue);
   unsigned char* misc = smem + L.misc;
@@ -390,7 +408,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
   }
   // the per-tile slide moves [T, T+H) to [0, H): park the zero history where the first slide picks it up
   for (int i = tid; i < HY; i += SYNC_THREADS) ys[sync_lp(i + T)] = mk(0.f, 0.f);
-  for (int i = tid; i < HM; i += SYNC_THREADS) ms[sync_lp(i + T)] = 0.0f;
+  for (int i = tid; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = 0.0f;
   const bool x_al16 = ((uintptr_t)p.x & 15) == 0;
   const bool y_al16 = ((uintptr_t)p.y & 15) == 0;
   // weight of this thread's 8 samples in the tile summary of the detector average
@@ -466,13 +484,12 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
         __syncthreads();
       }
     }
-    for (int i = tl; i < HM; i += SYNC_THREADS) ms[sync_lp(i)] = ms[sync_lp(i + T)];  // HM <= T (checked by the host)
     __syncthreads();  // B1
     STAMP(0);
 
     // prefetch the next tile of x; its latency hides behind the filter
     have_pre = false;
-    if (tile + 1 < tile_own1 && x_al16 && t0 + 2ull * T <= p.nsamples) {
+    if (SYNC_PREFETCH && tile + 1 < tile_own1 && x_al16 && t0 + 2ull * T <= p.nsamples) {
       const float4* src = reinterpret_cast<const float4*>(p.x + t0 + T);
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) xpre[r] = src[tl + r * SYNC_THREADS];
@@ -616,7 +633,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     block_scan3_sum3(tsum, anc, scA, &ex3, &anch);  // B3
     STAMP(4);
     float Mv[SYNC_V];
-    const int mb = sync_lp(HM + SYNC_V * tl);
+    const int mb = sync_lp(SYNC_V * tl);
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
       const float pre = anch.a + ex3.a + pfr[j];
@@ -628,7 +645,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
       if (!(m <= 1024.0f)) m = 1024.0f;
       if (masked && (t0s + SYNC_V * tl + j < mvalid)) m = 0.0f;
       Mv[j] = m;
-      ms[mb + j] = m;
+      mt[mb + j] = m;
     }
     __syncthreads();  // B4
     STAMP(5);
@@ -636,25 +653,30 @@ __global__ void __launch_bounds__(SYNC_THREADS, 2) k_sync(SyncParams p) {
     // ---- 5. CP-length moving average of M (float32), minus one -----------------------------
     float pm[SYNC_V];
     float msum = 0.f;
-    if ((CP & 7) == 0) {  // (HM - CP) is a multiple of 8: one base index, constant offsets
-      const int mo = sync_lp(HM - CP + SYNC_V * tl);
+    // M[n - CP] of sample i of the tile sits at position i of the sequence [history (HM = CP) | tile]
+    if ((CP & 7) == 0) {  // a thread's 8 values come from one array, at constant offsets from one base
+      const float* srcm = (SYNC_V * tl < HM) ? (mh + sync_lp(SYNC_V * tl)) : (mt + sync_lp(SYNC_V * tl - HM));
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
-        msum += Mv[j] - ms[mo + j];
+        msum += Mv[j] - srcm[j];
         pm[j] = msum;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
-        msum += Mv[j] - ms[sync_lp(HM + SYNC_V * tl + j - CP)];
+        const int i = SYNC_V * tl + j;
+        msum += Mv[j] - ((i < HM) ? mh[sync_lp(i)] : mt[sync_lp(i - HM)]);
         pm[j] = msum;
       }
     }
     float manc = 0.f;
-    for (int m = -CP + tl; m < 0; m += SYNC_THREADS) manc += ms[sync_lp(HM + m)];
+    for (int m = -CP + tl; m < 0; m += SYNC_THREADS) manc += mh[sync_lp(HM + m)];
     float mex, mach;
     block_scan1_sum1(msum, manc, scB, &mex, &mach);  // B5
     STAMP(6);
+    // the CP newest M values become the next tile's history (every thread has done its reads of mh
+    // and mt before B5; mt is free from here on)
+    for (int i = tl; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = mt[sync_lp(T - HM + i)];
     if (!owned) continue;  // warm-up tile: only the histories matter
 
     float u[SYNC_V];
