@@ -95,11 +95,19 @@ def _check_rx(orc, cfg, eng, x):
     # float stages: 1e-5 in units of the stage's signal scale
     # complex_to_arg is evaluated with the same float32 operations on both sides: the NCO's input is exact
     assert np.array_equal(eng.tap(_abi.TAP_RX_ANGLES), ro.tap(_abi.TAP_RX_ANGLES))
+    carriers = cfg.carrier_map.decode("ascii") or "FE7F"
+    data_cols = np.zeros(cfg.occupied_tones, bool)
+    data_cols[config.carrier_map(cfg.occupied_tones, cfg.occupied_tones, carriers)] = True
     for tap in (_abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK):
         a, b = ro.tap(tap), eng.tap(tap)
         assert a.shape == b.shape
         if a.size:
-            assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(a))), tap
+            tol = np.full(a.shape, 1e-5, np.float64)
+            if tap == _abi.TAP_RX_ACQ:
+                # carriers the map leaves empty hold noise times the equaliser gain (the sink never reads
+                # them): the two float32 FFTs may differ there by the gain times their rounding
+                tol[:, ~data_cols] = 1e-4
+            assert np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(a))), tap
     return pk
 
 
