@@ -375,9 +375,16 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, 3) k_rx_demod(Demod
       }
       c32 comp;
       {
-        const double a = -6.283185307179586476925 * (double)coarse * (double)q.CP / (double)N * (double)phase_count;
-        const float af = (float)a;
-        comp = mk(cosf(af), sinf(af));
+        // coarse == 0 (the common case): a = -0.0, cos = 1, sin = -0 exactly -- skip the transcendental
+        if (coarse != 0) {
+          const double a = -6.283185307179586476925 * (double)coarse * (double)q.CP / (double)N * (double)phase_count;
+          const float af = (float)a;
+          float sn, cs;
+          sincosf(af, &sn, &cs);
+          comp = mk(cs, sn);
+        } else {
+          comp = mk(1.0f, -0.0f);
+        }
         phase_count++;
         if (phase_count == 1000) phase_count = 1;
       }
@@ -397,7 +404,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, 3) k_rx_demod(Demod
         continue;
       }
       // demapper
-      const c32 carrier = mk(cosf(pll_phase), sinf(pll_phase));
+      c32 carrier;
+      sincosf(pll_phase, &carrier.im, &carrier.re);  // one range reduction for both
       float are = 0.f, aim = 0.f;
       const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
