@@ -56,28 +56,81 @@ def make_payload_blob(npkt, size, stream_id):
     return np.ascontiguousarray(blob.reshape(-1))
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box
+    shows all host cores in the mask but grants a 16-core share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(round(float(parts[0]) / float(parts[1])))))
+            else:
+                q = float(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(round(q / float(f.read())))))
+            break
+        except (IOError, OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(cfg, sigma, lead, tail, size, npkt):
-    """The oracle (a single-threaded C port of the reference flow graph) on a bounded sample of the
-    same workload, timed on this host's cores.  A reported baseline, not the optimisation target.
-    The sample's IQ is then pushed through the GPU receiver as the checker: same packets, same verdicts."""
+    """The oracle (a C port of the reference flow graph, one thread per stream) on a bounded sample of the
+    same workload, timed on this host's cores: first one stream on one core, then one independent stream per
+    core on all cores of the box's share.  A reported baseline, not the optimisation target.
+    The single-stream sample's IQ is then pushed through the GPU receiver as the checker: same packets, same
+    verdicts."""
+    import threading
     from oracle import oracle as orc
     from ofdm_uhd_amd import engine
-    blob = make_payload_blob(npkt, size, 0)
-    pay = [blob[i * size:(i + 1) * size].tobytes() for i in range(npkt)]
     orc.lib()
+
+    def one_stream(stream_id, n, out):
+        blob = make_payload_blob(n, size, stream_id)
+        pay = [blob[i * size:(i + 1) * size].tobytes() for i in range(n)]
+        iq = orc.tx(cfg, pay, lead=lead, tail=tail)
+        orc.channel(iq, sigma=sigma, seed=0xC0FFEE, stream_id=stream_id)
+        r = orc.rx(cfg, iq)
+        nsym = (len(iq) - lead - tail) // (cfg.fft_length + cfg.cp_length)
+        out[stream_id] = (nsym, sum(1 for o, _ in r.packets if o), iq if stream_id == 0 else None,
+                          r.packets if stream_id == 0 else None)
+
+    # (a) one stream, one core
+    res = {}
     t0 = time.perf_counter()
-    iq = orc.tx(cfg, pay, lead=lead, tail=tail)
-    orc.channel(iq, sigma=sigma, seed=0xC0FFEE, stream_id=0)
-    r = orc.rx(cfg, iq)
-    dt = time.perf_counter() - t0
-    nsym = (len(iq) - lead - tail) // (cfg.fft_length + cfg.cp_length)
-    ok = sum(1 for o, _ in r.packets if o)
+    one_stream(0, npkt, res)
+    dt1 = time.perf_counter() - t0
+    nsym1, ok1, iq, pkts = res[0]
     eng = engine.Engine(cfg=cfg)
-    same = eng.rx(iq) == r.packets
+    same = eng.rx(iq) == pkts
     eng.close()
-    return {"value": nsym / dt, "unit": "OFDM symbols/s", "cores": 1, "kind": "port",
-            "sample": "%d packets (%d symbols) of the same workload through oracle/ofdm_oracle.c, TX+AWGN+RX, "
-                      "1 thread, %.1f s; CRC pass %d/%d" % (npkt, nsym, dt, ok, npkt),
+    del iq
+    # (b) one stream per core (ctypes releases the GIL inside the oracle), a quarter of the sample each
+    cores = host_cores()
+    per = max(256, npkt // 4)
+    resn = {}
+    th = [threading.Thread(target=one_stream, args=(i + 1, per, resn)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dtn = time.perf_counter() - t0
+    nsymn = sum(v[0] for v in resn.values())
+    okn = sum(v[1] for v in resn.values())
+    return {"value": nsymn / dtn, "unit": "OFDM symbols/s", "cores": cores, "kind": "port",
+            "sample": "%d independent streams x %d packets (%d symbols) of the same workload through "
+                      "oracle/ofdm_oracle.c, TX+AWGN+RX, one thread per stream, %.1f s; CRC pass %d/%d"
+                      % (cores, per, nsymn, dtn, okn, cores * per),
+            "single_core": {"value": nsym1 / dt1, "cores": 1,
+                            "sample": "%d packets (%d symbols), %.1f s; CRC pass %d/%d" % (npkt, nsym1, dt1, ok1, npkt)},
             "gpu_rx_matches_on_sample": bool(same)}
 
 
@@ -221,6 +274,18 @@ def main():
         avg_s = (kms / max(klaunch, 1)) * 1e-3
         achieved = launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         path_bytes = 2 * L * 8.0 + 2 * bits_b                        # 10 339 B per symbol at C2
+        # HBM traffic of that kernel from the committed PMC passes of this same command (cannot be collected from
+        # inside the process): read + write bytes per symbol x symbols of one launch; null for other configs
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)) as f:
+                pmc = json.load(f)
+            bps = pmc["bytes_per_symbol"].get(kname)
+            if bps:
+                traffic = (bps["read"] + bps["write"]) * nsym
+                traffic_src = pmc["source"]
+        except (IOError, OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "OFDM symbols/sec (TX+loopback RX) @ N_fft=512; packet CRC pass rate",
             "value": sym_per_s,
@@ -240,7 +305,8 @@ def main():
             "crc_pass_rate": g["crc_ok"] / float(max(world * P * args.steps, 1)),
             "crc_ok_payloads_bit_exact": all_exact,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": kname,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname,
                          "kernel_avg_ms": kms / max(klaunch, 1), "algorithmic_bytes_per_launch": launch_bytes,
                          "path_achieved": sym_per_s / world * path_bytes / 1e9,
                          "path_frac": sym_per_s / world * path_bytes / 1e9 / HBM_PEAK_GBPS},

@@ -50,7 +50,7 @@ struct SyncParams {
   int ntaps_pad;  // multiple of 8
   int tiles_per_seg, nwarm;
   int exact_all;  // metric tap: evaluate every sample in fixed point
-  int ablate;     // timing experiments only (OFDM_ABLATE): 1 skip filter taps, 2 skip metric, 4 skip y store
+  int ablate;     // diagnostic build only (-DSYNC_DIAG, see SYNC_ABLATE): 1 skip filter taps, 2 skip metric, 4 skip y store
   unsigned long long* stamps;  // diagnostic build (-DSYNC_STAMPS): [wg][8] cycles per phase of wave 0
   uint64_t nsamples, ntiles;
   float tapcp;       // float(1/CP)
@@ -360,6 +360,13 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 #ifndef SYNC_PREFETCH
 #define SYNC_PREFETCH 1
 #endif
+// Phase ablation for timing experiments exists only in the diagnostic build (make diag ->
+// libofdm_hip_diag.so, selected with OFDM_HIP_LIB); the product library always runs every phase.
+#ifdef SYNC_DIAG
+#define SYNC_ABLATE(p, bit) ((p).ablate & (bit))
+#else
+#define SYNC_ABLATE(p, bit) 0
+#endif
 template <int U>
 __global__ void __launch_bounds__(SYNC_THREADS, 3) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
@@ -505,7 +512,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 3) k_sync(SyncParams p) {
       // compiler (static indices, no moves); it is re-read from LDS at the top of every iteration so
       // that nothing but one index is carried around the loop.  The taps of an iteration sit in SGPRs.
       int gw = gb;
-      for (int kb = 0; kb < ((p.ablate & 1) ? 8 * U : p.ntaps_pad); kb += 8 * U) {
+      for (int kb = 0; kb < (SYNC_ABLATE(p, 1) ? 8 * U : p.ntaps_pad); kb += 8 * U) {
         c32 w[15];  // w[d] = x[out0 - kb - 7 + d]
 #pragma unroll
         for (int d = 0; d < 7; d++) w[d] = xs[gw + 1 + d];
@@ -544,7 +551,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 3) k_sync(SyncParams p) {
     for (int i = tl; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
 
     // ---- 3. y to HBM (owned tiles only), coalesced from LDS ----------------------------
-    if (owned && !(p.ablate & 4)) {
+    if (owned && !SYNC_ABLATE(p, 4)) {
       if (y_al16 && t0 + (uint64_t)T <= p.nsamples) {
         float4* dst = reinterpret_cast<float4*>(p.y + t0);
 #pragma unroll
@@ -564,7 +571,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, 3) k_sync(SyncParams p) {
       }
     }
 
-    if (p.ablate & 2) {
+    if (SYNC_ABLATE(p, 2)) {
       __syncthreads();
       continue;
     }

@@ -1,3 +1,5 @@
+# needs the diagnostic library: make -C ofdm_uhd_amd/csrc diag (built before the gpurun call)
+export OFDM_HIP_LIB=${GRAFT_REPO_ROOT:-$PWD}/ofdm_uhd_amd/csrc/libofdm_hip_diag.so
 # usage: bash tools/ablate_pmc.sh  -- VALU/SALU/LDS instruction counts of k_sync under the OFDM_ABLATE phases
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
