@@ -233,6 +233,24 @@ int ofdm_sense_device_msgs(ofdm_handle *h, void **d_msgs, uint64_t *nmsgs, uint3
  * ofdm_rx_sense_result.  Both calls order themselves after the sensing kernels. */
 int ofdm_sense_redecide(ofdm_handle *h, const ofdm_sense_cfg *sc);
 
+/* --- chunked streams -------------------------------------------------------------
+ * ofdm_rx treats each call as one stream that starts at its first sample (filter and
+ * correlator history zero, detector average 0, NCO phase 0), as the reference's flow graph
+ * does at start-up.  A continuous capture is fed in overlapping chunks; these three entry
+ * points give the caller what it needs to stitch them so that the result equals one call on
+ * the whole capture (ofdm_uhd_amd/ofdm.py: ofdm_demod.feed / flush do exactly that):
+ *  - the flag sample (last sample of the preamble symbol, relative to the call's iq) of every
+ *    packet the last call delivered, in delivery order;
+ *  - the flags of the last call with the NCO phase and per-sample phase step in force from
+ *    each flag on: phi[n] = phi_j + step_j * (n - flag_j + 1)  (gr_frequency_modulator_fc
+ *    driven by the sample-and-held sync angle, ofdm_receiver.py~:97-124);
+ *  - a phase reference for the following calls: the first flag at or after ref_sample
+ *    (relative to that call's iq; may be negative) gets phi + step * (flag - ref_sample),
+ *    i.e. the NCO continues where the previous chunk left it. */
+int ofdm_rx_packet_pos(ofdm_handle *h, uint64_t *pos, int cap, int *n);
+int ofdm_rx_nco_state(ofdm_handle *h, uint64_t *flags, double *phi, double *step, int cap, int *n);
+int ofdm_rx_set_nco_ref(ofdm_handle *h, int enable, int64_t ref_sample, double phi, double step);
+
 /* --- debug taps: the reference's --log probe points (ofdm.py:123-131,253-254;
  *     ofdm_receiver.py~:144-152).  Enable before the call, read after.  Output
  *     is always copied to HOST memory. ---------------------------------------- */

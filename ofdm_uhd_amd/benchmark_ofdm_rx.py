@@ -41,6 +41,9 @@ def main(argv=None):
     parser.add_option("", "--snr", type="eng_float", default=30, help="set the SNR of the channel in dB [default=%default]")
     parser.add_option("", "--from-file", default="ofdm_tx.dat", help="IQ file to demodulate [default=%default]")
     parser.add_option("", "--to-file", default="rx1.txt", help="write received file contents here [default=%default]")
+    parser.add_option("", "--chunk-samples", type="eng_float", default=0,
+                      help="stream the capture through the demodulator in chunks of this many samples "
+                           "(0 = one call on the whole file) [default=%default]")
     receive_path.receive_path.add_options(parser, expert_grp)
     ofdm.ofdm_demod.add_options(parser, expert_grp)
     (options, args) = parser.parse_args(argv)
@@ -51,7 +54,7 @@ def main(argv=None):
     packet_file = open(options.to_file, 'wb')
     acct = rx_accounting(packet_file)
     rxpath = receive_path.receive_path(acct.rx_callback, options)
-    rxpath.run(iqio.file_source(options.from_file))
+    rxpath.run(iqio.file_source(options.from_file), chunk_samples=int(options.chunk_samples))
     packet_file.close()
     return acct
 

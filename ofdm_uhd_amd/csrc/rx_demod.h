@@ -567,6 +567,9 @@ struct DeframeParams {
   uint64_t* out_off;  // [max_pkts+1]
   uint32_t* out_len;  // [max_pkts]
   uint8_t* out_ok;    // [max_pkts]
+  uint64_t* out_pos;  // [max_pkts] flag sample of the packet's preamble
+  const uint64_t* peaks;  // flags of the stream; frame f belongs to peaks[j0 + f]
+  uint32_t j0;
   uint32_t max_pkts;
   uint8_t* raw_tap;       // optional: concatenated messages before dewhitening
   uint64_t* counters;     // [0] headers_ok [1] packets [2] crc_ok [3] chained [4] capacity overflow
@@ -681,6 +684,7 @@ __global__ void __launch_bounds__(256) k_deframe_write(DeframeParams q) {
     q.out_off[ord] = boff;
     q.out_len[ord] = plen;
     q.out_ok[ord] = (uint8_t)ok;  // (packet / CRC totals are summed by the host from these flags)
+    q.out_pos[ord] = q.peaks[q.j0 + f];
   }
 }
 
@@ -702,20 +706,45 @@ __global__ void __launch_bounds__(256) k_raw_len(DeframeParams q, uint64_t* __re
   lens[f] = l;
 }
 
+// NCO phase reference of a chunked stream: the first flag at or after `ref` shall carry the phase
+// phi_ref + step_ref * (flag - ref); every Phi of the call moves by the same amount.
+__global__ void k_nco_find(const uint64_t* __restrict__ peaks, const double* __restrict__ Phi, uint64_t npeaks, int64_t ref,
+                           double phi_ref, double step_ref, double* __restrict__ delta) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint64_t lo = 0, hi = npeaks;  // first index with peaks[i] >= ref
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if ((int64_t)peaks[mid] < ref) lo = mid + 1;
+    else hi = mid;
+  }
+  double d = 0.0;
+  if (lo < npeaks) d = phi_ref + step_ref * (double)((int64_t)peaks[lo] - ref) - Phi[lo];
+  *delta = d;
+}
+__global__ void __launch_bounds__(256) k_nco_add(double* __restrict__ Phi, uint64_t npeaks, const double* __restrict__ delta) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npeaks) Phi[i] += *delta;
+}
+
 // ------------------------------------------------------------------------------------
 // receive-side workspaces
 // ------------------------------------------------------------------------------------
 struct RxState {
   DevBuf x_stage, y, metric, tile_B, tile_np, tile_first, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
       partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
-      out_payload, out_off, out_len, out_ok, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
+      out_payload, out_off, out_len, out_ok, out_pos, nco_delta, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
+  std::vector<uint64_t> last_pos;  // host copy: flag sample of every packet of the last call
+  // NCO phase reference for chunked streams (ofdm_rx_set_nco_ref)
+  bool nco_ref_on = false;
+  int64_t nco_ref_peak = 0;
+  double nco_ref_phi = 0.0, nco_ref_step = 0.0;
   void release() {
     DevBuf* all[] = {&x_stage, &y,      &metric,  &tile_B,   &tile_np,  &tile_first, &tile_pieces, &avg_in,     &cand_u,
                      &cand_P,  &counters, &counts, &offsets,  &partial,  &peaks,       &peak_P,     &angle,
                      &step,    &inc,    &Phi,     &K,        &nsym,     &sym_base,    &res,        &raw,
                      &invalid, &chain_list, &key, &pos,      &out_payload, &out_off,  &out_len,    &out_ok,
-                     &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
+                     &out_pos, &nco_delta, &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
     for (DevBuf* b : all) b->release();
   }
 };

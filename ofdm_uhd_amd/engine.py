@@ -221,6 +221,33 @@ class Engine(object):
         n = npk.value
         return n, off[:n + 1], ln[:n], ok[:n]
 
+    # -- chunked streams --------------------------------------------------------------
+    def rx_packet_pos(self):
+        """Flag sample (relative to the last rx() call's IQ) of every packet it delivered."""
+        n = C.c_int(0)
+        self._check(self._lib.ofdm_rx_packet_pos(self._h, None, 0, C.byref(n)))
+        pos = np.zeros(max(n.value, 1), np.uint64)
+        if n.value:
+            self._check(self._lib.ofdm_rx_packet_pos(self._h, _ptr(pos), n.value, C.byref(n)))
+        return pos[:n.value]
+
+    def rx_nco_state(self):
+        """(flags uint64, phi float64, step float64) of the last rx() call."""
+        n = C.c_int(0)
+        self._check(self._lib.ofdm_rx_nco_state(self._h, None, None, None, 0, C.byref(n)))
+        k = n.value
+        fl, phi, st = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.float64), np.zeros(max(k, 1), np.float64)
+        if k:
+            self._check(self._lib.ofdm_rx_nco_state(self._h, _ptr(fl), _ptr(phi), _ptr(st), k, C.byref(n)))
+        return fl[:k], phi[:k], st[:k]
+
+    def set_nco_ref(self, ref_sample=None, phi=0.0, step=0.0):
+        """NCO phase reference for the following rx() calls (None switches it off)."""
+        if ref_sample is None:
+            self._check(self._lib.ofdm_rx_set_nco_ref(self._h, 0, 0, 0.0, 0.0))
+        else:
+            self._check(self._lib.ofdm_rx_set_nco_ref(self._h, 1, int(ref_sample), float(phi), float(step)))
+
     # -- spectrum sensing ----------------------------------------------------------
     def _sense_outputs(self, sc, nm, nd):
         S = sc.fft_size

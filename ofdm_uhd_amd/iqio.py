@@ -65,6 +65,18 @@ class file_source(object):
     def read_all(self):
         return read_complex_binary(self.filename)
 
+    def read_chunks(self, chunk_samples):
+        """The file in pieces of chunk_samples (the last one shorter), without loading it whole."""
+        off = 0
+        while True:
+            a = read_complex_binary(self.filename, count=chunk_samples, offset_samples=off)
+            if len(a) == 0:
+                return
+            yield a
+            off += len(a)
+            if len(a) < chunk_samples:
+                return
+
 
 class vector_source(object):
     def __init__(self, iq):
@@ -72,3 +84,7 @@ class vector_source(object):
 
     def read_all(self):
         return self._iq
+
+    def read_chunks(self, chunk_samples):
+        for a in range(0, len(self._iq), chunk_samples):
+            yield self._iq[a:a + chunk_samples]

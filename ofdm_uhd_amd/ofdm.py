@@ -9,7 +9,10 @@ GPU call and writes the samples to the connected sink; ``ofdm_demod.work(iq)``
 demodulates one contiguous IQ stream and fires ``callback(ok, payload)`` once per
 recovered packet, in stream order, on the caller's thread.
 """
+import math
 import sys
+
+import numpy as np
 
 from . import config, engine, iqio, ofdm_packet_utils  # noqa: F401  (ofdm_packet_utils re-exported like digital.ofdm_packet_utils)
 from .config import known_symbols_4512_3  # noqa: F401  (ofdm.py:310-325)
@@ -191,6 +194,88 @@ class ofdm_demod(object):
 
     def run(self, source):
         return self.work(source.read_all())
+
+    # -- continuous operation: the flow graph never stops, captures arrive in chunks ------------------
+    #
+    # The engine demodulates one contiguous array per call and starts every call like the flow graph
+    # starts (zero filter / correlator history, detector average 0, NCO phase 0).  feed() stitches
+    # chunks so that the packets equal those of ONE call on the whole capture:
+    #   * each call sees [carried tail | new chunk]; the tail starts on the sync kernel's tile grid and
+    #     reaches back far enough (the detector average looks back 34 tiles; the first tiles of a call
+    #     lack correlator history; a packet begun before the horizon can swallow later frames) for
+    #     everything after the previous horizon to be detected exactly as in the uncut stream;
+    #   * packets whose preamble flag lies beyond `horizon` = end of data minus one maximum-length
+    #     packet are held back (their symbols may continue in the next chunk) and come out of the next
+    #     call; packets at or before the previous horizon were delivered already and are skipped;
+    #   * the NCO continues from the last final flag (phase and step carried over).
+    def _stream_geometry(self):
+        cfg = self._engine.cfg
+        N, CP = cfg.fft_length, cfg.cp_length
+        L = N + CP
+        T = 2048                                         # SYNC_TILE of csrc/rx_sync.h
+        nbits = max(1, int(math.ceil(math.log(cfg.arity, 2))))
+        ncar = len(config.carrier_map(cfg.occupied_tones, cfg.occupied_tones, cfg.carrier_map.decode("ascii") or "FE7F"))
+        sym_max = int(math.ceil(8.0 * (4 + 4095 + 17) / (ncar * nbits))) + 1
+        span = (sym_max + 3) * L + 2 * T + int(cfg.ntaps)
+        lookback = (34 + 3 + (L + T - 1) // T) * T
+        return T, span, lookback
+
+    def reset_stream(self):
+        self._s_tail = np.zeros(0, np.complex64)   # samples carried into the next call
+        self._s_abs = 0                            # absolute index of _s_tail[0]
+        self._s_final = -1                         # every flag <= this absolute index has been dealt with
+        self._s_ref = None                         # (abs flag, phi, step): NCO state at the last final flag
+        self._engine.set_nco_ref(None)
+
+    def feed(self, iq, flush=False):
+        """Demodulate the next chunk of a continuous capture; returns the packets that became final.
+        ``flush=True`` (or flush()) ends the stream: everything still held back is delivered."""
+        if not hasattr(self, "_s_tail"):
+            self.reset_stream()
+        T, span, lookback = self._stream_geometry()
+        iq = np.ascontiguousarray(iq, np.complex64)
+        buf = np.concatenate([self._s_tail, iq]) if len(self._s_tail) else iq
+        base = self._s_abs
+        total = base + len(buf)
+        horizon = total if flush else total - span           # flags <= horizon are final after this call
+        out = []
+        if len(buf) and horizon > self._s_final:
+            eng = self._engine
+            if self._s_ref is not None:
+                eng.set_nco_ref(self._s_ref[0] - base, self._s_ref[1], self._s_ref[2])
+            pkts = eng.rx(buf)
+            pos = eng.rx_packet_pos().astype(np.int64) + base
+            for (ok, payload), p in zip(pkts, pos):
+                if self._s_final < p <= horizon:
+                    out.append((ok, payload))
+            fl, phi, st = eng.rx_nco_state()
+            fl = fl.astype(np.int64) + base
+            sel = np.flatnonzero(fl <= horizon)
+            if len(sel):
+                j = int(sel[-1])
+                if fl[j] > (self._s_ref[0] if self._s_ref else -1):
+                    self._s_ref = (int(fl[j]), float(phi[j]), float(st[j]))
+            self._s_final = max(self._s_final, horizon)
+        if flush:
+            self.reset_stream()
+        else:
+            # carry: one maximum packet (a packet that began before the horizon may swallow frames after
+            # it) plus the detector's look-back before the horizon, on the tile grid of the absolute stream
+            start = max(base, ((horizon - lookback - span) // T) * T) if horizon > 0 else base
+            self._s_tail = buf[start - base:].copy()
+            self._s_abs = start
+        if self._log:
+            self._write_logs()
+        for ok, payload in out:
+            self.n_packets += 1
+            if ok:
+                self.n_ok += 1
+            if self._callback:
+                self._callback(ok, payload)
+        return out
+
+    def flush(self):
+        return self.feed(np.zeros(0, np.complex64), flush=True)
 
     def reset_carrier_map(self, carrier_map_new):
         """The frame sink's side of reset_carrier_map: streams demodulated from now on are

@@ -20,8 +20,24 @@ class receive_path(object):
     def work(self, iq):
         return self.ofdm_rx.work(iq)
 
-    def run(self, source):
-        return self.ofdm_rx.run(source)
+    def run(self, source, chunk_samples=None):
+        """Demodulate a whole source; with ``chunk_samples`` it is streamed through ofdm_demod.feed
+        in pieces of that size (same packets, bounded memory)."""
+        if not chunk_samples or not hasattr(source, "read_chunks"):
+            return self.ofdm_rx.run(source)
+        out = []
+        for piece in source.read_chunks(int(chunk_samples)):
+            out += self.ofdm_rx.feed(piece)
+        out += self.ofdm_rx.flush()
+        return out
+
+    def feed(self, iq, flush=False):
+        """Continuous operation (what the radio source does in the reference): next chunk in,
+        packets that became final out; see ofdm_demod.feed."""
+        return self.ofdm_rx.feed(iq, flush)
+
+    def flush(self):
+        return self.ofdm_rx.flush()
 
     def add_options(normal, expert):
         normal.add_option("-v", "--verbose", action="store_true", default=False)

@@ -27,6 +27,10 @@ def test_benchmark_file_loopback(tmp_path):
     acct = benchmark_ofdm_rx.main(["--from-file", iqf, "--to-file", out])
     assert acct.n_rcvd == npk and acct.n_right == npk
     assert open(out, "rb").read() == data
+    # the same capture streamed in 100k-sample chunks: same file out
+    out2 = str(tmp_path / "rx2.txt")
+    acct2 = benchmark_ofdm_rx.main(["--from-file", iqf, "--to-file", out2, "--chunk-samples", "100k"])
+    assert (acct2.n_rcvd, acct2.n_right) == (npk, npk) and open(out2, "rb").read() == data
 
 
 def test_ofdm_mod_demod_objects():
