@@ -11,13 +11,18 @@
 //
 // LDS layout: point i lives at index i + i/8 (one pad per 8 points) which makes
 // the strided Stockham stores and the unit-stride loads conflict-free for
-// ds_{read,write}_b64.  Two buffers alternate so each exchange costs one barrier.
+// ds_{read,write}_b64.  Up to N = 1024 two buffers alternate so each exchange costs one
+// barrier.  From N = 2048 on a transform works in ONE buffer (every middle pass reads all its
+// inputs, meets a second barrier, then writes in place): 37 KB instead of 74 KB at N = 4096
+// doubles the workgroups a CU can hold, which is what hides the barriers of these 4-pass sizes.
 #pragma once
 #include "common.h"
 
 __host__ __device__ constexpr int fft_lds_points(int n) { return n + n / 8; }
-// LDS bytes one transform needs (two buffers)
-__host__ __device__ constexpr int fft_lds_bytes(int n) { return 2 * fft_lds_points(n) * (int)sizeof(c32); }
+__host__ __device__ constexpr bool fft_onebuf(int n) { return n >= 2048; }
+__host__ __device__ constexpr int fft_lds_bufs(int n) { return fft_onebuf(n) ? 1 : 2; }
+// LDS bytes one transform needs
+__host__ __device__ constexpr int fft_lds_bytes(int n) { return fft_lds_bufs(n) * fft_lds_points(n) * (int)sizeof(c32); }
 
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
 
@@ -85,10 +90,14 @@ __device__ __forceinline__ c32 tw_get(const c32* __restrict__ tw, int idx) {
 // FROM_REG: inputs are e[m] = x[t + m*N/8]; otherwise read from `src` (padded LDS).
 // TO_REG  : outputs end in e[m] = X[t + m*N/8] (only legal for the last pass);
 //           otherwise written to `dst` (padded LDS).
-template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG>
-__device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* dst, const c32* __restrict__ tw) {
+// INPLACE: dst == src; `sync` is called between the last read and the first write (radix 8 only:
+//           one butterfly per thread, so all of a thread's reads precede all of its writes).
+template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG, bool INPLACE = false, typename SyncFn = int>
+__device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* dst, const c32* __restrict__ tw,
+                                         SyncFn sync = 0) {
   constexpr int T = N / 8;        // threads per transform
   constexpr int NB = 8 / R;       // butterflies per thread
+  static_assert(!INPLACE || (NB == 1 && !FROM_REG && !TO_REG), "in-place passes are radix-8 middle passes");
   constexpr int STRIDE = N / R;   // input stride of one butterfly
 #pragma unroll
   for (int b = 0; b < NB; b++) {
@@ -116,6 +125,7 @@ __device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* d
       dft2(v[0], v[1]);
     }
     const int obase = (j - k) * R + k;  // (j / LS) * LS * R + k
+    if constexpr (INPLACE) sync();
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (TO_REG)
@@ -164,21 +174,23 @@ __device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __
     fft_pass<1024, 8, 16, INV, false, false>(e, t, B, A, tw);
     sync();
     fft_pass<1024, 8, 128, INV, false, true>(e, t, A, nullptr, tw);
-  } else if constexpr (N == 2048) {
+  } else if constexpr (N == 2048) {  // one buffer
+    (void)B;
     fft_pass<2048, 4, 1, INV, true, false>(e, t, nullptr, A, tw);
     sync();
-    fft_pass<2048, 8, 4, INV, false, false>(e, t, A, B, tw);
+    fft_pass<2048, 8, 4, INV, false, false, true>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<2048, 8, 32, INV, false, false>(e, t, B, A, tw);
+    fft_pass<2048, 8, 32, INV, false, false, true>(e, t, A, A, tw, sync);
     sync();
     fft_pass<2048, 8, 256, INV, false, true>(e, t, A, nullptr, tw);
-  } else {
+  } else {  // one buffer
     static_assert(N == 4096, "unsupported FFT length");
+    (void)B;
     fft_pass<4096, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
     sync();
-    fft_pass<4096, 8, 8, INV, false, false>(e, t, A, B, tw);
+    fft_pass<4096, 8, 8, INV, false, false, true>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<4096, 8, 64, INV, false, false>(e, t, B, A, tw);
+    fft_pass<4096, 8, 64, INV, false, false, true>(e, t, A, A, tw, sync);
     sync();
     fft_pass<4096, 8, 512, INV, false, true>(e, t, A, nullptr, tw);
   }

@@ -192,14 +192,19 @@ __device__ __noinline__ dc dexpj(double ph) {
   return r;
 }
 
+#ifndef DEMOD_WAVES
+#define DEMOD_WAVES 3  // waves per SIMD the register allocation aims at (measured best of 2 / 3 / 4)
+#endif
 template <int N>
-__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, 3) k_rx_demod(DemodParams q) {
+__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_demod(DemodParams q) {
   constexpr int T = N / 8;
   extern __shared__ __align__(16) unsigned char smem[];
   c32* fftbuf = reinterpret_cast<c32*>(smem);
   c32* Ysh = fftbuf;  // the first FFT buffer is free again after the last pass: shifted spectrum, linear
-  float* sd = reinterpret_cast<float*>(fftbuf + fft_lds_points(N));  // second FFT buffer, free between transforms
-  c32* hinv = fftbuf + 2 * fft_lds_points(N);
+  c32* hinv = fftbuf + fft_lds_bufs(N) * fft_lds_points(N);
+  // correlator scratch (occ + 2*shift + 1 floats): the second FFT buffer where there is one, else the
+  // equaliser's own array -- it is rebuilt from scratch right after the correlation (block barriers between)
+  float* sd = fft_onebuf(N) ? reinterpret_cast<float*>(hinv) : reinterpret_cast<float*>(fftbuf + fft_lds_points(N));
   c32* dfe = hinv + q.occ;
   c32* cst = dfe + q.occ;
   float* red = reinterpret_cast<float*>(cst + q.arity);
@@ -321,13 +326,14 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, 3) k_rx_demod(Demod
       // ---- digital_ofdm_frame_acquisition ------------------------------------------------------
       if (k == 0) {
         phase_count = 1;
-        // correlate(): sd[i] = |Y[i] - Y[i+2]|^2
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-          const int i = t + m * T;
+        // correlate(): sd[i] = |Y[i] - Y[i+2]|^2, kept only over the bins the search below reads:
+        // sdl[r] = sd[zl - shift + r], r < occ + 2*shift  (0 outside [0, N-2), as the reference's zero padding)
+        const int sbase = q.zl - q.shift, slen = q.occ + 2 * q.shift;
+        for (int r = t; r < slen; r += T) {
+          const int i = sbase + r;
           float v = 0.f;
-          if (i < N - 2) v = cnorm(csub(Ysh[i], Ysh[i + 2]));
-          sd[i] = v;
+          if (i >= 0 && i < N - 2) v = cnorm(csub(Ysh[i], Ysh[i + 2]));
+          sd[r] = v;
         }
         __syncthreads();
         int index = 0;
@@ -336,9 +342,9 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, 3) k_rx_demod(Demod
           float pa = 0.f, pb = 0.f;
           for (int jj = t; jj < q.occ; jj += T) {
             const float kdv = q.kd[jj];
-            const int qa = i0 + jj, qb = i0 + 1 + jj;
-            pa = pa + kdv * ((qa >= 0 && qa < N) ? sd[qa] : 0.f);
-            pb = pb + kdv * ((qb >= 0 && qb < N) ? sd[qb] : 0.f);
+            const int ra = i0 - sbase + jj;  // in [0, slen - 1)
+            pa = pa + kdv * sd[ra];
+            pb = pb + kdv * sd[ra + 1];
           }
           block_sum2_f<T>(pa, pb, red);
           if (pa > mx) {

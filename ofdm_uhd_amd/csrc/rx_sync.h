@@ -367,8 +367,11 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 #else
 #define SYNC_ABLATE(p, bit) 0
 #endif
-template <int U>
-__global__ void __launch_bounds__(SYNC_THREADS, 3) k_sync(SyncParams p) {
+// U: tap blocks per filter iteration.  W: workgroups per CU the register allocation aims at -- 3 when the
+// LDS footprint allows three (<= 53 KB, e.g. C2), else 2 (long symbols: the y history alone is N+CP samples),
+// where the larger register budget avoids the spills the 3-workgroup build accepts.
+template <int U, int W>
+__global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
     w[m] = p.win[t + m * TPT];
     mx[m] = 0.0f;  // reset_stats()
   }
-  c32* my = lds + (size_t)g * 2 * fft_lds_points(NS);
+  c32* my = lds + (size_t)g * fft_lds_bufs(NS) * fft_lds_points(NS);
   const uint32_t stride = p.nsplit * G;
   // every group of the workgroup runs the same number of rounds (barriers inside fft_run)
   const uint32_t rounds = (p.dwell_delay + stride - 1) / stride;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
              uint64_t nsym, uint64_t lead, c32* __restrict__ out, c32* __restrict__ freq_tap) {
   constexpr int T = TxGeom<N>::T, SPW = TxGeom<N>::SPW;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  c32* lds = reinterpret_cast<c32*>(smem_raw) + (threadIdx.x / T) * (2 * fft_lds_points(N));
+  c32* lds = reinterpret_cast<c32*>(smem_raw) + (threadIdx.x / T) * (fft_lds_bufs(N) * fft_lds_points(N));
   const int t = threadIdx.x % T;
   uint64_t sym = (uint64_t)blockIdx.x * SPW + threadIdx.x / T;
   const bool active = sym < nsym;
