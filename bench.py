@@ -114,7 +114,7 @@ def cpu_baseline(cfg, sigma, lead, tail, size, npkt):
     del iq
     # (b) one stream per core (ctypes releases the GIL inside the oracle), a quarter of the sample each
     cores = host_cores()
-    per = max(256, npkt // 4)
+    per = max(256, npkt // 2)
     resn = {}
     th = [threading.Thread(target=one_stream, args=(i + 1, per, resn)) for i in range(cores)]
     t0 = time.perf_counter()
@@ -153,7 +153,12 @@ def main():
 
     from ofdm_uhd_amd import _abi, config, engine, options, parallel
 
-    rank, local_rank, world = parallel.init_process_group()
+    # OFDM_BENCH_REHEARSE=1: rehearse the multi-rank path on a ONE-GPU box -- gloo instead of RCCL and every
+    # rank on cuda:0 (RCCL refuses two ranks on one device).  Never set by the driver; numbers are meaningless.
+    rehearse = os.environ.get("OFDM_BENCH_REHEARSE") == "1"
+    rank, local_rank, world = parallel.init_process_group("gloo" if rehearse else None)
+    if rehearse:
+        local_rank = 0
     if world != max(args.gpus, 1) and rank == 0:
         sys.stderr.write("warning: --gpus %d but WORLD_SIZE %d\n" % (args.gpus, world))
     if not torch.cuda.is_available():
