@@ -242,14 +242,22 @@ int ofdm_sense_redecide(ofdm_handle *h, const ofdm_sense_cfg *sc);
  *  - the flag sample (last sample of the preamble symbol, relative to the call's iq) of every
  *    packet the last call delivered, in delivery order;
  *  - the flags of the last call with the NCO phase and per-sample phase step in force from
- *    each flag on: phi[n] = phi_j + step_j * (n - flag_j + 1)  (gr_frequency_modulator_fc
- *    driven by the sample-and-held sync angle, ofdm_receiver.py~:97-124);
- *  - a phase reference for the following calls: the first flag at or after ref_sample
- *    (relative to that call's iq; may be negative) gets phi + step * (flag - ref_sample),
- *    i.e. the NCO continues where the previous chunk left it. */
+ *    each flag on: phi[n] = phase_j + step_j * (n - flag_j + 1)  (gr_frequency_modulator_fc
+ *    driven by the sample-and-held sync angle, ofdm_receiver.py~:97-124).  phase_j is an
+ *    integer, units of 2^-64 turn: phases add modulo one turn without rounding, which is what
+ *    makes chunked and one-shot processing agree to the last bit; swallowed_j != 0 says the
+ *    flag's frame was consumed as payload of a packet that began at an earlier flag;
+ *  - the settled past for the following calls: the flags at or before trust_after (relative to
+ *    the next call's iq, ascending, inside it) that earlier calls found, with their phase
+ *    steps and swallowed marks -- they replace whatever that call detects up to trust_after, in the start of its
+ *    overlap where its own detector has not settled -- and the NCO line (phase, step at
+ *    pred_flag, which may be negative) of the flag before them, in force up to the call's
+ *    first flag.  enable = 0 returns to independent calls. */
 int ofdm_rx_packet_pos(ofdm_handle *h, uint64_t *pos, int cap, int *n);
-int ofdm_rx_nco_state(ofdm_handle *h, uint64_t *flags, double *phi, double *step, int cap, int *n);
-int ofdm_rx_set_nco_ref(ofdm_handle *h, int enable, int64_t ref_sample, double phi, double step);
+int ofdm_rx_nco_state(ofdm_handle *h, uint64_t *flags, uint64_t *phase, double *step, uint8_t *swallowed,
+                      int cap, int *n);
+int ofdm_rx_set_flag_history(ofdm_handle *h, int enable, int n, const int64_t *flags, const double *steps,
+                             const uint8_t *swallowed, int64_t trust_after, int64_t pred_flag, uint64_t pred_phase, double pred_step);
 
 /* --- debug taps: the reference's --log probe points (ofdm.py:123-131,253-254;
  *     ofdm_receiver.py~:144-152).  Enable before the call, read after.  Output

@@ -39,12 +39,30 @@ struct FramesParams {
   const c32* peak_P;
   float* angle;     // [npeaks]
   double* step;     // [npeaks]
-  double* inc;      // [npeaks] phase advance until the next flag
+  uint64_t* inc;    // [npeaks] phase advance until the next flag, in units of 2^-64 turn (see nco_turns)
   uint32_t* K;      // [npeaks] data symbols of the frame
   uint64_t* nsym;   // [npeaks] K+1 for accepted frames else 0 (scanned into symbol ordinals)
   unsigned int* n_lo;   // flags before the sampler's first window (p < N)
   unsigned int* n_hi;   // flags the sampler never reaches (end of stream)
+  // chunked streams (ofdm_rx_set_flag_history): the first nforced flags were settled by earlier calls and
+  // carry their known phase step instead of one derived from this call's correlator output
+  uint64_t nforced;
+  const double* forced_step;
 };
+
+// NCO phase bookkeeping across flags is done in integers: a phase advance x (radians) becomes
+// frac(x / 2 pi) * 2^64 and phases add modulo 2^64 = modulo one turn.  Integer addition is associative, so
+// the device-wide scan gives the same phases whatever its shape -- one call on a whole capture and the
+// chunked calls of ofdm_demod.feed() agree to the last bit -- and the wrapped phase keeps full precision
+// however long the stream runs.
+__host__ __device__ __forceinline__ uint64_t nco_turns(double x) {
+  double t = x * 0.15915494309189533577;  // 1 / (2 pi)
+  t -= floor(t);
+  return (uint64_t)(t * 18446744073709551616.0);  // t < 1: exact scaling, no overflow
+}
+__host__ __device__ __forceinline__ double nco_radians(uint64_t u) {
+  return (double)(int64_t)u * 3.4061215800865545e-19;  // 2 pi / 2^64: phase in [-pi, pi)
+}
 
 __device__ __forceinline__ uint32_t sampler_K(uint64_t p, bool has_next, uint64_t nxt, uint64_t ns, int L, uint32_t timeout) {
   uint64_t k = (uint64_t)timeout + 1;
@@ -68,11 +86,12 @@ __global__ void __launch_bounds__(256) k_frames(FramesParams q) {
   const c32 P = q.peak_P[j];
   const float ang = det_atan2f(P.im, P.re);  // complex_to_arg, bit-reproducible form
   q.angle[j] = ang;
-  const double st = (double)(q.sens * ang);
+  double st = (double)(q.sens * ang);
+  if (j < q.nforced) st = q.forced_step[j];
   q.step[j] = st;
   const bool has_next = j + 1 < q.npeaks;
   const uint64_t nxt = has_next ? q.peaks[j + 1] : 0;
-  q.inc[j] = has_next ? st * (double)(nxt - p) : 0.0;
+  q.inc[j] = has_next ? nco_turns(st * (double)(nxt - p)) : 0ull;
 
   const uint64_t N = (uint64_t)q.N, L = (uint64_t)q.L;
   bool accept = p >= N;
@@ -127,6 +146,10 @@ struct DemodParams {
   c32* tap_acq;            // optional [nsym][occ]
   c32* tap_sink;           // optional [nsym][occ]
   uint8_t* tap_demapped;   // optional [nsym]
+  // NCO state carried in from the previous chunk: in force before the first flag of this call
+  int ref_on;
+  int64_t ref_peak;
+  double ref_phi, ref_step;
 };
 
 // LDS of one frame's workgroup: fft (2 buffers; the first doubles as the shifted spectrum, the second as
@@ -259,6 +282,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       const double stq = q.step[j - 1];
       Ap = dexpj(q.Phi[j - 1] + stq * (double)((int64_t)(s00 + (uint64_t)t) - (int64_t)q.peaks[j - 1] + 1));
       RTp = dexpj(stq * (double)T);
+    } else if (pre_simple && q.ref_on) {
+      // chunked streams: what precedes this call's first flag runs on the NCO line carried in
+      Ap = dexpj(q.ref_phi + q.ref_step * (double)((int64_t)(s00 + (uint64_t)t) - q.ref_peak + 1));
+      RTp = dexpj(q.ref_step * (double)T);
     }
 
     // prefetch of the next symbol's samples
@@ -307,7 +334,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
           int64_t i = (int64_t)j;
           while (i >= 0 && q.peaks[i] > n) i--;
           double ph = 0.0;
-          if (i >= 0) ph = q.Phi[i] + q.step[i] * (double)(n - q.peaks[i] + 1);
+          if (i >= 0)
+            ph = q.Phi[i] + q.step[i] * (double)(n - q.peaks[i] + 1);
+          else if (q.ref_on)
+            ph = q.ref_phi + q.ref_step * (double)((int64_t)n - q.ref_peak + 1);
           const dc r = dexpj(ph);
           e[m] = cmul(e[m], mk((float)r.re, (float)r.im));
         }
@@ -527,10 +557,15 @@ __global__ void __launch_bounds__(256) k_chain_collect(const FrameResult* __rest
 }
 
 // single thread: sort the (short) list of chain heads, walk it, mark swallowed frames
+// `pre` (chunked streams): the first npre frames were settled by earlier calls -- pre[f] != 0 says frame f was
+// swallowed by a packet that began before it (possibly before this call's first sample): it is invalid and is
+// no chain head here either.
 __global__ void k_chain_resolve(const FrameResult* __restrict__ res, uint32_t nframes, uint32_t* __restrict__ list,
                                 uint32_t cap, const unsigned int* __restrict__ count, uint8_t* __restrict__ invalid,
-                                unsigned int* overflow) {
+                                unsigned int* overflow, const uint8_t* __restrict__ pre, uint32_t npre) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (uint32_t f = 0; f < npre && f < nframes; f++)
+    if (pre[f]) invalid[f] = 1;
   unsigned int n = *count;
   if (n > cap) {
     atomicOr(overflow, 2u);
@@ -549,6 +584,7 @@ __global__ void k_chain_resolve(const FrameResult* __restrict__ res, uint32_t nf
   for (unsigned int i = 0; i < n; i++) {
     const uint32_t f = list[i];
     if ((int64_t)f <= cover) continue;  // itself swallowed: its optimistic result does not count
+    if (f < npre && pre[f]) continue;   // swallowed by a packet of an earlier chunk
     const uint32_t e = res[f].end_frame;
     for (uint32_t g = f + 1; g <= e && g < nframes; g++) invalid[g] = 1;
     cover = (int64_t)e;
@@ -712,24 +748,19 @@ __global__ void __launch_bounds__(256) k_raw_len(DeframeParams q, uint64_t* __re
   lens[f] = l;
 }
 
-// NCO phase reference of a chunked stream: the first flag at or after `ref` shall carry the phase
-// phi_ref + step_ref * (flag - ref); every Phi of the call moves by the same amount.
-__global__ void k_nco_find(const uint64_t* __restrict__ peaks, const double* __restrict__ Phi, uint64_t npeaks, int64_t ref,
-                           double phi_ref, double step_ref, double* __restrict__ delta) {
-  if (blockIdx.x || threadIdx.x) return;
-  uint64_t lo = 0, hi = npeaks;  // first index with peaks[i] >= ref
-  while (lo < hi) {
-    const uint64_t mid = (lo + hi) >> 1;
-    if ((int64_t)peaks[mid] < ref) lo = mid + 1;
-    else hi = mid;
-  }
-  double d = 0.0;
-  if (lo < npeaks) d = phi_ref + step_ref * (double)((int64_t)peaks[lo] - ref) - Phi[lo];
-  *delta = d;
-}
-__global__ void __launch_bounds__(256) k_nco_add(double* __restrict__ Phi, uint64_t npeaks, const double* __restrict__ delta) {
+// Phases of the flags from their scanned integer advances.  Chunked streams: the line carried in from the
+// flag that precedes this call's first one (phase ref_u at sample ref, step step_ref) is in force up to
+// that first flag, which therefore starts from ref_u + turns(step_ref * (flag0 - ref)).
+__global__ void __launch_bounds__(256) k_nco_phase(const uint64_t* __restrict__ peaks, const uint64_t* __restrict__ acc,
+                                                    uint64_t npeaks, int ref_on, int64_t ref, uint64_t ref_u, double step_ref,
+                                                    uint64_t* __restrict__ Phi_u, double* __restrict__ Phi) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npeaks) Phi[i] += *delta;
+  if (i >= npeaks) return;
+  uint64_t off = 0;
+  if (ref_on) off = ref_u + nco_turns(step_ref * (double)((int64_t)peaks[0] - ref));
+  const uint64_t u = acc[i] + off;
+  Phi_u[i] = u;
+  Phi[i] = nco_radians(u);
 }
 
 // ------------------------------------------------------------------------------------
@@ -738,19 +769,25 @@ __global__ void __launch_bounds__(256) k_nco_add(double* __restrict__ Phi, uint6
 struct RxState {
   DevBuf x_stage, y, metric, tile_B, tile_np, tile_first, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
       partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
-      out_payload, out_off, out_len, out_ok, out_pos, nco_delta, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
+      out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
   std::vector<uint64_t> last_pos;  // host copy: flag sample of every packet of the last call
-  // NCO phase reference for chunked streams (ofdm_rx_set_nco_ref)
+  // chunked streams (ofdm_rx_set_flag_history): flags settled by earlier calls replace whatever this call
+  // detects up to trust_after; the NCO line of the flag before them
   bool nco_ref_on = false;
-  int64_t nco_ref_peak = 0;
-  double nco_ref_phi = 0.0, nco_ref_step = 0.0;
+  int64_t nco_ref_peak = 0, nco_trust_after = 0;
+  uint64_t nco_ref_u = 0;
+  double nco_ref_step = 0.0;
+  std::vector<uint64_t> hist_flags;
+  std::vector<double> hist_steps;
+  std::vector<uint8_t> hist_swallowed;
+  std::vector<uint8_t> last_swallowed;  // per flag of the last call: its frame was swallowed by an earlier packet
   void release() {
     DevBuf* all[] = {&x_stage, &y,      &metric,  &tile_B,   &tile_np,  &tile_first, &tile_pieces, &avg_in,     &cand_u,
                      &cand_P,  &counters, &counts, &offsets,  &partial,  &peaks,       &peak_P,     &angle,
                      &step,    &inc,    &Phi,     &K,        &nsym,     &sym_base,    &res,        &raw,
                      &invalid, &chain_list, &key, &pos,      &out_payload, &out_off,  &out_len,    &out_ok,
-                     &out_pos, &nco_delta, &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
+                     &out_pos, &inc_acc, &Phi_u, &peaks2, &peak_P2, &fstep, &pre_inv, &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
     for (DevBuf* b : all) b->release();
   }
 };

@@ -232,21 +232,30 @@ class Engine(object):
         return pos[:n.value]
 
     def rx_nco_state(self):
-        """(flags uint64, phi float64, step float64) of the last rx() call."""
+        """(flags uint64, phase uint64 in 2^-64 turn, step float64, swallowed uint8) of the last rx() call."""
         n = C.c_int(0)
-        self._check(self._lib.ofdm_rx_nco_state(self._h, None, None, None, 0, C.byref(n)))
+        self._check(self._lib.ofdm_rx_nco_state(self._h, None, None, None, None, 0, C.byref(n)))
         k = n.value
-        fl, phi, st = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.float64), np.zeros(max(k, 1), np.float64)
+        fl, phi = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.uint64)
+        st, sw = np.zeros(max(k, 1), np.float64), np.zeros(max(k, 1), np.uint8)
         if k:
-            self._check(self._lib.ofdm_rx_nco_state(self._h, _ptr(fl), _ptr(phi), _ptr(st), k, C.byref(n)))
-        return fl[:k], phi[:k], st[:k]
+            self._check(self._lib.ofdm_rx_nco_state(self._h, _ptr(fl), _ptr(phi), _ptr(st), _ptr(sw), k, C.byref(n)))
+        return fl[:k], phi[:k], st[:k], sw[:k]
 
-    def set_nco_ref(self, ref_sample=None, phi=0.0, step=0.0):
-        """NCO phase reference for the following rx() calls (None switches it off)."""
-        if ref_sample is None:
-            self._check(self._lib.ofdm_rx_set_nco_ref(self._h, 0, 0, 0.0, 0.0))
-        else:
-            self._check(self._lib.ofdm_rx_set_nco_ref(self._h, 1, int(ref_sample), float(phi), float(step)))
+    def set_flag_history(self, flags=None, steps=None, swallowed=None, trust_after=-1, pred=(0, 0, 0.0)):
+        """The settled past for the following rx() calls (flags=None switches it off): ``flags`` /
+        ``steps`` / ``swallowed`` replace what a call detects up to ``trust_after``; ``pred`` = (flag,
+        phase, step) of the flag before them (may lie before the call's first sample)."""
+        if flags is None:
+            self._check(self._lib.ofdm_rx_set_flag_history(self._h, 0, 0, None, None, None, 0, 0, 0, 0.0))
+            return
+        fl = np.ascontiguousarray(flags, np.int64)
+        st = np.ascontiguousarray(steps, np.float64)
+        sw = np.ascontiguousarray(swallowed, np.uint8)
+        k = len(fl)
+        self._check(self._lib.ofdm_rx_set_flag_history(self._h, 1, k, _ptr(fl) if k else None, _ptr(st) if k else None,
+                                                       _ptr(sw) if k else None, int(trust_after), int(pred[0]),
+                                                       int(pred[1]), float(pred[2])))
 
     # -- spectrum sensing ----------------------------------------------------------
     def _sense_outputs(self, sc, nm, nd):

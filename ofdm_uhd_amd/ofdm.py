@@ -181,6 +181,8 @@ class ofdm_demod(object):
     def work(self, iq):
         """Demodulate one contiguous IQ stream; fires the callback per packet and returns the
         list of (ok, payload)."""
+        if hasattr(self, "_s_tail"):
+            self.reset_stream()  # a one-shot call ends any chunked stream (and drops its NCO reference)
         pkts = self._engine.rx(iq)
         if self._log:
             self._write_logs()
@@ -224,8 +226,10 @@ class ofdm_demod(object):
         self._s_tail = np.zeros(0, np.complex64)   # samples carried into the next call
         self._s_abs = 0                            # absolute index of _s_tail[0]
         self._s_final = -1                         # every flag <= this absolute index has been dealt with
-        self._s_ref = None                         # (abs flag, phi, step): NCO state at the last final flag
-        self._engine.set_nco_ref(None)
+        # settled flags still of interest: (abs flag, phase in 2^-64 turn, step, swallowed); before any flag
+        # the NCO idles at phase 0
+        self._s_hist = [(0, 0, 0.0, 0)]
+        self._engine.set_flag_history(None)
 
     def feed(self, iq, flush=False):
         """Demodulate the next chunk of a continuous capture; returns the packets that became final.
@@ -241,20 +245,22 @@ class ofdm_demod(object):
         out = []
         if len(buf) and horizon > self._s_final:
             eng = self._engine
-            if self._s_ref is not None:
-                eng.set_nco_ref(self._s_ref[0] - base, self._s_ref[1], self._s_ref[2])
+            # the settled past: flags inside this buffer keep their known steps (whatever the call re-detects
+            # in its unsettled overlap is dropped); the last one before the buffer is the NCO's predecessor
+            inside = [f for f in self._s_hist if f[0] >= max(base, 1)]
+            before = [f for f in self._s_hist if f[0] < max(base, 1)]
+            pred = before[-1] if before else (0, 0, 0.0, 0)
+            eng.set_flag_history([f[0] - base for f in inside], [f[2] for f in inside], [f[3] for f in inside],
+                                 trust_after=self._s_final - base, pred=(pred[0] - base, pred[1], pred[2]))
             pkts = eng.rx(buf)
             pos = eng.rx_packet_pos().astype(np.int64) + base
             for (ok, payload), p in zip(pkts, pos):
                 if self._s_final < p <= horizon:
                     out.append((ok, payload))
-            fl, phi, st = eng.rx_nco_state()
+            fl, phi, st, sw = eng.rx_nco_state()
             fl = fl.astype(np.int64) + base
-            sel = np.flatnonzero(fl <= horizon)
-            if len(sel):
-                j = int(sel[-1])
-                if fl[j] > (self._s_ref[0] if self._s_ref else -1):
-                    self._s_ref = (int(fl[j]), float(phi[j]), float(st[j]))
+            for j in np.flatnonzero((fl > self._s_final) & (fl <= horizon)):
+                self._s_hist.append((int(fl[j]), int(phi[j]), float(st[j]), int(sw[j])))
             self._s_final = max(self._s_final, horizon)
         if flush:
             self.reset_stream()
@@ -264,6 +270,10 @@ class ofdm_demod(object):
             start = max(base, ((horizon - lookback - span) // T) * T) if horizon > 0 else base
             self._s_tail = buf[start - base:].copy()
             self._s_abs = start
+            # history: the flags of the carried part and the last one before it
+            keep = [f for f in self._s_hist if f[0] >= max(start, 1)]
+            older = [f for f in self._s_hist if f[0] < max(start, 1)]
+            self._s_hist = older[-1:] + keep
         if self._log:
             self._write_logs()
         for ok, payload in out:
