@@ -81,10 +81,13 @@ __global__ void k_sym_desc(const uint64_t* __restrict__ sym_off, int npkt, uint3
 // ---------------------------------------------------------------------------------
 // modulator.  WG = max(256, N/8) threads = SPW symbols of N/8 threads each.
 // ---------------------------------------------------------------------------------
+#ifndef TX_MIN_WG
+#define TX_MIN_WG 256  // (64 = one symbol per workgroup at N = 512 measured the same: the kernel is bound by the noise generator)
+#endif
 template <int N>
 struct TxGeom {
   static constexpr int T = N / 8;
-  static constexpr int WG = (T > 256) ? T : 256;
+  static constexpr int WG = (T > TX_MIN_WG) ? T : TX_MIN_WG;
   static constexpr int SPW = WG / T;
 };
 
