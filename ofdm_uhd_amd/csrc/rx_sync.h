@@ -499,7 +499,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 
     // prefetch the next tile of x; its latency hides behind the filter
     have_pre = false;
-    if (SYNC_PREFETCH && tile + 1 < tile_own1 && x_al16 && t0 + 2ull * T <= p.nsamples) {
+    // (register prefetch only in the 2-workgroup build: at 168 VGPRs one of its four vectors was spilled
+    //  to scratch and back every tile -- 2.5 KB of HBM traffic per symbol for nothing; three resident
+    //  workgroups hide the load latency by themselves)
+    if (SYNC_PREFETCH && W < 3 && tile + 1 < tile_own1 && x_al16 && t0 + 2ull * T <= p.nsamples) {
       const float4* src = reinterpret_cast<const float4*>(p.x + t0 + T);
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) xpre[r] = src[tl + r * SYNC_THREADS];
