@@ -1,6 +1,6 @@
-"""Replay a capture saved by tools/fuzz_stream.py and show where feed() and the one-shot call part ways."""
+"""Replay a capture saved by tests/soak/fuzz_stream.py and show where feed() and the one-shot call part ways."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from ofdm_uhd_amd import ofdm, options, _abi

@@ -1,6 +1,6 @@
-"""Worst float deviations GPU vs oracle per RX tap for one parity case: python tools/diag_tol.py"""
+"""Worst float deviations GPU vs oracle per RX tap for one parity case: python tests/soak/diag_tol.py"""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import loopback_stream, make_cfg, make_payloads

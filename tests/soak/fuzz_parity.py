@@ -1,7 +1,7 @@
 """Randomised parity soak: engine vs oracle over random geometries, constellations, packet mixes, SNR,
-carrier offsets, carrier maps and stream lengths.  python tools/fuzz_parity.py [seconds] [seed]"""
+carrier offsets, carrier maps and stream lengths.  python tests/soak/fuzz_parity.py [seconds] [seed]"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import make_cfg, make_payloads

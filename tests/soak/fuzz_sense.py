@@ -1,6 +1,6 @@
-"""Randomised soak of the spectrum sensor: engine vs oracle.  python tools/fuzz_sense.py [seconds] [seed]"""
+"""Randomised soak of the spectrum sensor: engine vs oracle.  python tests/soak/fuzz_sense.py [seconds] [seed]"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import make_cfg

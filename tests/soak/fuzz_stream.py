@@ -1,7 +1,7 @@
 """Randomised soak of ofdm_demod.feed(): random captures cut into random chunks must give the one-shot packets.
-python tools/fuzz_stream.py [seconds] [seed]"""
+python tests/soak/fuzz_stream.py [seconds] [seed]"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import make_cfg, make_payloads

@@ -2,7 +2,8 @@
 """Stage-by-stage parity of the HIP engine against the CPU oracle (run on the GPU box).
 Prints one line per stage; used while bringing kernels up.  tests/ holds the asserting version."""
 import os, sys, struct, time, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 import numpy as np
 from ofdm_uhd_amd import config, options, _abi, engine
 from oracle import oracle as orc
