@@ -329,7 +329,7 @@ def main():
                               "k_sense_GBps": used / (sms / max(sl, 1) * 1e-3) / 1e9 if sms > 0 else None,
                               "overlapped_with": "k_sync (second HIP stream)",
                               "fusion": "max over ranks (all_reduce)" if world > 1 else "single antenna"}
-        if args.cpu_packets > 0:
+        if args.cpu_packets > 0 and world == 1:      # the CPU leg runs at N=1 only (rank 0 would hold the others up)
             cfg_host = config.make_cfg(opt)
             out["cpu_baseline"] = cpu_baseline(cfg_host, sigma, lead, tail, size, args.cpu_packets)
         else:
