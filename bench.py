@@ -210,7 +210,8 @@ def main():
         eng.set_rx_sense(sc)
 
     def step():
-        n = eng.tx_device(d_blob.data_ptr(), offs, lens, d_iq.data_ptr(), nsamp)
+        # TX is only queued; RX follows it on the engine's stream and ends with the step's synchronisation
+        n = eng.tx_device(d_blob.data_ptr(), offs, lens, d_iq.data_ptr(), nsamp, wait=False)
         tx_stats = dict(eng.last_stats)
         npk, off, ln, ok = eng.rx_device(d_iq.data_ptr(), n, d_out.data_ptr(), d_out.numel(), max_pkts)
         rx_stats = dict(eng.last_stats)

@@ -167,6 +167,17 @@ int ofdm_tx(ofdm_handle *h, const uint8_t *payloads, const uint64_t *payload_off
             const uint32_t *payload_len, int npkt, ofdm_c32 *iq_out, uint64_t iq_cap,
             uint64_t *nsamples, ofdm_stats *stats /* may be NULL */);
 
+/* the same, returning as soon as the work is queued on the handle's stream: the samples are complete after
+ * ofdm_wait() -- or for whatever the caller queues behind them on that stream, e.g. ofdm_rx() on the same
+ * handle reading iq_out (device-pointer mode: a TX -> RX loopback then has no host round trip in between).
+ * The host metadata arrays may be reused at once; in host-pointer mode iq_out must not be read before ofdm_wait.
+ * One asynchronous call may be outstanding per handle: ofdm_wait (or any synchronous call on the handle, all
+ * of which end with a stream synchronisation) must come before the next ofdm_tx_async. */
+int ofdm_tx_async(ofdm_handle *h, const uint8_t *payloads, const uint64_t *payload_off,
+                  const uint32_t *payload_len, int npkt, ofdm_c32 *iq_out, uint64_t iq_cap,
+                  uint64_t *nsamples, ofdm_stats *stats /* may be NULL */);
+int ofdm_wait(ofdm_handle *h);
+
 /* standalone channel on an existing IQ buffer (same generator as the fused one;
  * sample n of the buffer is stream sample index0+n) */
 int ofdm_channel(ofdm_handle *h, ofdm_c32 *iq, uint64_t n, const ofdm_chan *chan, uint64_t index0);

@@ -102,7 +102,7 @@ class ofdm_sense_cfg(C.Structure):
 EXPORTS = (
     "ofdm_abi_version", "ofdm_device_count", "ofdm_create", "ofdm_destroy", "ofdm_last_error",
     "ofdm_set_stream", "ofdm_set_tx_amplitude", "ofdm_set_carrier_map", "ofdm_set_channel", "ofdm_framed_len",
-    "ofdm_make_packets", "ofdm_tx_frame_count", "ofdm_tx", "ofdm_channel", "ofdm_rx",
+    "ofdm_make_packets", "ofdm_tx_frame_count", "ofdm_tx", "ofdm_tx_async", "ofdm_wait", "ofdm_channel", "ofdm_rx",
     "ofdm_set_taps", "ofdm_tap", "ofdm_prof_enable", "ofdm_prof_reset", "ofdm_prof_get",
     "ofdm_kernel_name", "ofdm_sense_count", "ofdm_sense", "ofdm_sense_decide", "ofdm_set_rx_sense",
     "ofdm_rx_sense_result", "ofdm_sense_device_msgs", "ofdm_sense_redecide",
@@ -133,6 +133,8 @@ def _declare(lib):
     lib.ofdm_make_packets.argtypes = [H, u8p, u64p, u32p, C.c_int, u8p, C.c_uint64, u64p]
     lib.ofdm_tx_frame_count.argtypes = [H, u32p, C.c_int, u64p, u64p]
     lib.ofdm_tx.argtypes = [H, u8p, u64p, u32p, C.c_int, vp, C.c_uint64, u64p, C.POINTER(ofdm_stats)]
+    lib.ofdm_tx_async.argtypes = lib.ofdm_tx.argtypes
+    lib.ofdm_wait.argtypes = [H]
     lib.ofdm_channel.argtypes = [H, vp, C.c_uint64, C.POINTER(ofdm_chan), C.c_uint64]
     lib.ofdm_rx.argtypes = [H, vp, C.c_uint64, u8p, C.c_uint64, u64p, u32p, C.POINTER(C.c_uint8),
                             C.c_int, C.POINTER(C.c_int), C.POINTER(ofdm_stats)]

@@ -553,8 +553,9 @@ static int launch_noise(ofdm_handle* h, c32* d_iq, uint64_t n, uint64_t index0, 
   return OFDM_OK;
 }
 
-extern "C" int ofdm_tx(ofdm_handle* h, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* payload_len,
-                       int npkt, ofdm_c32* iq_out, uint64_t iq_cap, uint64_t* nsamples, ofdm_stats* stats) {
+// everything of ofdm_tx up to, not including, the final synchronisation
+static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* payload_len,
+                      int npkt, ofdm_c32* iq_out, uint64_t iq_cap, uint64_t* nsamples, ofdm_stats* stats) {
   if (!h) return OFDM_E_INVAL;
   if (npkt < 0 || (npkt && (!payloads || !payload_off || !payload_len)) || !nsamples) FAIL(h, OFDM_E_INVAL, "null argument");
   bool uni;
@@ -625,9 +626,27 @@ extern "C" int ofdm_tx(ofdm_handle* h, const uint8_t* payloads, const uint64_t* 
     if (rc) return rc;
   }
   if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(iq_out, d_out, total * sizeof(c32), hipMemcpyDeviceToHost, h->stream));
+  return OFDM_OK;
+}
+
+extern "C" int ofdm_wait(ofdm_handle* h) {
+  if (!h) return OFDM_E_INVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->prof.collect();
   return OFDM_OK;
+}
+
+extern "C" int ofdm_tx(ofdm_handle* h, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* payload_len,
+                       int npkt, ofdm_c32* iq_out, uint64_t iq_cap, uint64_t* nsamples, ofdm_stats* stats) {
+  int rc = tx_enqueue(h, payloads, payload_off, payload_len, npkt, iq_out, iq_cap, nsamples, stats);
+  if (rc != OFDM_OK) return rc;
+  return ofdm_wait(h);
+}
+
+extern "C" int ofdm_tx_async(ofdm_handle* h, const uint8_t* payloads, const uint64_t* payload_off, const uint32_t* payload_len,
+                             int npkt, ofdm_c32* iq_out, uint64_t iq_cap, uint64_t* nsamples, ofdm_stats* stats) {
+  return tx_enqueue(h, payloads, payload_off, payload_len, npkt, iq_out, iq_cap, nsamples, stats);
 }
 
 extern "C" int ofdm_channel(ofdm_handle* h, ofdm_c32* iq, uint64_t n, const ofdm_chan* chan, uint64_t index0) {

@@ -163,12 +163,19 @@ class Engine(object):
         self.last_stats = st.as_dict()
         return iq[:ns.value]
 
-    def tx_device(self, payload_ptr, offs, lens, iq_ptr, iq_cap):
-        """Device mode: payload bytes and IQ are device pointers; offs/lens are NumPy host arrays."""
+    def wait(self):
+        """Block until everything queued on the handle's stream (tx_device(wait=False)) is done."""
+        self._check(self._lib.ofdm_wait(self._h))
+
+    def tx_device(self, payload_ptr, offs, lens, iq_ptr, iq_cap, wait=True):
+        """Device mode: payload bytes and IQ are device pointers; offs/lens are NumPy host arrays.
+        ``wait=False`` only queues the work (ofdm_tx_async): a following rx_device() on the same engine
+        is ordered behind it on the stream, so a TX -> RX loopback needs no host round trip in between."""
         assert self.device_ptrs
         ns = C.c_uint64(0)
         st = _abi.ofdm_stats()
-        self._check(self._lib.ofdm_tx(self._h, C.c_void_p(payload_ptr), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+        fn = self._lib.ofdm_tx if wait else self._lib.ofdm_tx_async
+        self._check(fn(self._h, C.c_void_p(payload_ptr), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
                                       lens.ctypes.data_as(C.POINTER(C.c_uint32)), len(lens), C.c_void_p(iq_ptr),
                                       int(iq_cap), C.byref(ns), C.byref(st)))
         self.last_stats = st.as_dict()

@@ -138,5 +138,14 @@ def test_device_pointer_mode_matches_host_mode():
     assert npk == 64 and bool(ok.all())
     assert [out[int(off[i]):int(off[i]) + int(ln[i])].tobytes() for i in range(npk)] == pay
     assert eh.rx(iq_h) == [(True, p) for p in pay]
+    # queued TX (ofdm_tx_async) followed by RX on the same stream: no host round trip in between, same result
+    d_iq2 = torch.zeros_like(d_iq)
+    d_pay2 = torch.zeros_like(d_pay)
+    n2 = ed.tx_device(d_blob.data_ptr(), offs, lens, d_iq2.data_ptr(), len(iq_h), wait=False)
+    npk2, off2, ln2, ok2 = ed.rx_device(d_iq2.data_ptr(), n2, d_pay2.data_ptr(), d_pay2.numel(), 100)
+    assert n2 == n and npk2 == 64 and bool(ok2.all()) and torch.equal(d_iq2, d_iq) and torch.equal(d_pay2, d_pay)
+    ed.tx_device(d_blob.data_ptr(), offs, lens, d_iq2.data_ptr(), len(iq_h), wait=False)
+    ed.wait()
+    assert torch.equal(d_iq2, d_iq)
     eh.close()
     ed.close()
