@@ -328,7 +328,7 @@ def main():
                               "last_carrier_map_head": (last_hex[0] or "")[:64],
                               "k_sense_avg_ms": sms / max(sl, 1),
                               "k_sense_GBps": used / (sms / max(sl, 1) * 1e-3) / 1e9 if sms > 0 else None,
-                              "overlapped_with": "k_sync (second HIP stream)",
+                              "overlapped_with": "the peak-detector pass, after k_sync (second HIP stream)",
                               "fusion": "max over ranks (all_reduce)" if world > 1 else "single antenna"}
         if args.cpu_packets > 0 and world == 1:      # the CPU leg runs at N=1 only (rank 0 would hold the others up)
             cfg_host = config.make_cfg(opt)
