@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OFDM_ABI_VERSION 2
+#define OFDM_ABI_VERSION 3
 
 #define OFDM_MAX_FFT 4096
 #define OFDM_MAX_CARRIER_HEX 1024 /* hex digits of a carrier map: OFDM_MAX_FFT / 4 */

@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"`` or ``make -C ofdm_uhd_amd/csrc``).
 import ctypes as C
 import os
 
-OFDM_ABI_VERSION = 2
+OFDM_ABI_VERSION = 3
 OFDM_MAX_FFT = 4096
 OFDM_MAX_TAPS = 512
 OFDM_MAX_ARITY = 256
