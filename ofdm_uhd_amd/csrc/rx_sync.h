@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       const float r = anch.c + ex3.c + pfe[j];
       const float num = fmaf(pre, pre, pim * pim);
       const float den = r * r;
-      float m = (den > 0.0f) ? __fdividef(num, den) : 0.0f;
+      float m = (den > 0.0f) ? num * __builtin_amdgcn_rcpf(den) : 0.0f;  // pre-selection only: 1-ulp reciprocal (an IEEE divide costs ten instructions)
       if (!(m <= 1024.0f)) m = 1024.0f;
       if (masked && (t0s + SYNC_V * tl + j < mvalid)) m = 0.0f;
       Mv[j] = m;
