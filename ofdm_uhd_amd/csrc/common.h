@@ -180,7 +180,8 @@ __device__ __forceinline__ c32 channel_apply(c32 x, uint64_t idx, float sigma, f
     // Box-Muller on the hardware transcendental units: v_log_f32 (log2) and v_sin/v_cos_f32, whose
     // argument is in revolutions -- exactly u2.  A few 1e-7 off libm, scaled by sigma: far below the
     // float32 resolution of the signal it is added to.
-    const float rad = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln(u1) = -2 ln2 log2(u1)
+    // (v_sqrt_f32 like the other three: 1 ulp, against a dozen instructions for the correctly rounded root)
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln(u1) = -2 ln2 log2(u1)
     const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
     const float s = sigma * 0.70710678118654752440f;
     x.re = x.re + s * (rad * cs);

@@ -106,8 +106,14 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
 
   uint32_t pkt, s;
   if (uniform_spp) {
-    pkt = (uint32_t)(sym / uniform_spp);
-    s = (uint32_t)(sym % uniform_spp);
+    if (nsym <= 0xFFFFFFFFull) {  // (always, in practice) 32-bit divide: a quarter of the 64-bit sequence
+      const uint32_t s32 = (uint32_t)sym;
+      pkt = s32 / uniform_spp;
+      s = s32 - pkt * uniform_spp;
+    } else {
+      pkt = (uint32_t)(sym / uniform_spp);
+      s = (uint32_t)(sym % uniform_spp);
+    }
   } else {
     pkt = sym_pkt[sym];
     s = (uint32_t)(sym - sym_off[pkt]);
@@ -121,23 +127,26 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
   } else {
     const uint8_t* msg = framed + framed_off[pkt];
     const uint32_t mlen = (uint32_t)(framed_off[pkt + 1] - framed_off[pkt]);
-    const uint64_t slot0 = (uint64_t)(s - 1) * (uint64_t)p.nc;
+    // bit positions fit 32 bits: a packet holds at most 4 105 bytes
+    const uint32_t msgbits = 8u * mlen;
+    const uint32_t nb = (uint32_t)p.nbits, bmask = (1u << nb) - 1u;
+    const uint32_t bit0 = (s - 1) * (uint32_t)p.nc * nb;  // first message bit of this symbol (may pass the end)
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int k = (t + m * T + N / 2) & (N - 1);  // ifftshift folded into the index
       const int car = p.bin2car[k];
       c32 v = mk(0.0f, 0.0f);
       if (car >= 0) {
-        const uint64_t slot = slot0 + (uint64_t)car;
-        const uint64_t b0 = slot * (uint64_t)p.nbits;
+        const uint32_t b0 = bit0 + (uint32_t)car * nb;
         uint32_t bits;
-        if (b0 + (uint64_t)p.nbits <= 8ull * mlen) {
+        if (bit0 <= msgbits && b0 + nb <= msgbits) {
           // LSB-first bit stream cut into nbits chunks (digital_ofdm_mapper_bcv::work)
-          const uint32_t byte = (uint32_t)(b0 >> 3);
+          const uint32_t byte = b0 >> 3;
           uint32_t w = msg[byte];
           if (byte + 1 < mlen) w |= (uint32_t)msg[byte + 1] << 8;
-          bits = (w >> (b0 & 7)) & ((1u << p.nbits) - 1u);
+          bits = (w >> (b0 & 7)) & bmask;
         } else {
+          const uint64_t slot = (uint64_t)(s - 1) * (uint64_t)p.nc + (uint64_t)car;
           bits = pad_symbol_hash(p.pad_seed, pkt, slot, (uint32_t)p.arity);  // rand() % arity stand-in
         }
         v = p.constellation[bits];
