@@ -149,3 +149,27 @@ def test_device_pointer_mode_matches_host_mode():
     assert torch.equal(d_iq2, d_iq)
     eh.close()
     ed.close()
+
+
+def test_metric_above_threshold_everywhere(orc):
+    """A carrier / constant / periodic input puts the Schmidl-Cox metric above the candidate threshold on
+    every sample: the sparse candidate buffers overflow and the receiver re-runs its sync pass with room for
+    all of them.  Same result as the oracle: no frames -- and the packets of a burst next to a long carrier."""
+    cfg = make_cfg("qpsk")
+    eng = _engine(cfg)
+    n = 300000
+    rng = np.random.default_rng(2)
+    for x in (np.ones(n, np.complex64), np.exp(2j * np.pi * 0.01 * np.arange(n)).astype(np.complex64),
+              np.tile((rng.standard_normal(256) + 1j * rng.standard_normal(256)).astype(np.complex64), n // 256)):
+        ro = orc.rx(cfg, x)
+        assert eng.rx(x) == ro.packets == []
+        assert eng.last_stats["peaks"] == ro.stats["peaks"] and eng.last_stats["overflow"] == 0
+    pay = make_payloads(6, 600, seed=4)
+    burst = loopback_stream(orc, cfg, pay, snr_db=30.0)
+    tone = (0.1 * np.exp(2j * np.pi * 0.013 * np.arange(250000))).astype(np.complex64)
+    x = np.concatenate([burst, tone, burst])
+    ro = orc.rx(cfg, x)
+    got = eng.rx(x)
+    assert got == ro.packets and eng.last_stats["peaks"] == ro.stats["peaks"]
+    assert sum(ok for ok, _ in got) >= 10
+    eng.close()
