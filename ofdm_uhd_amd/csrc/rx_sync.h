@@ -732,11 +732,11 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     }
     const int anyc = __syncthreads_or(amask != 0);  // B6
     STAMP(7);
-    if (tl == 0) {
+    if (tl == 0 && !anyc) {
       p.tile_B[tile] = (double)((scC[0] + scC[1]) + (scC[2] + scC[3]));
-      if (!anyc) p.tile_npieces[tile] = 0;
+      p.tile_npieces[tile] = 0;
     }
-    if (!anyc) continue;
+    if (!anyc) continue;  // (a tile with candidates gets its summary below, from the exact values)
 
     // ================= rare path: something near the threshold in this tile =================
     if (tl == 0) {
@@ -833,6 +833,11 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
       pre = aff_then(pre, prev);
     }
+    // Tile summary of the detector's average from the values just used: exact u wherever the metric is near
+    // or above the threshold, float32 only where it is small.  (Where the window energy drops by 50-60 dB inside
+    // a tile the float32 sums lose the small R to cancellation -- M = |P|^2/R^2 is then large AND a few percent
+    // off, enough to move the average that later tiles inherit.)
+    if (tl == SYNC_THREADS - 1) p.tile_B[tile] = aff_then(pre, f).b;
     const unsigned prevbit = (tl > 0) ? ((cm[tl - 1] >> 7) & 1u) : 0u;
     const unsigned nextbit = (tl < SYNC_THREADS - 1) ? (cm[tl + 1] & 1u) : 0u;
     const unsigned ext = (cmask << 1) | prevbit;           // bit j+1 = cand[j], bit 0 = cand[-1]

@@ -55,6 +55,13 @@ while time.time() < t_end:
         core = iq_o if len(iq_o) else np.ones(1, np.complex64)
         sigma = float(np.sqrt(np.mean(np.abs(core) ** 2) / 10 ** (snr / 10)))
         orc.channel(x, sigma=sigma, cfo=cfo * 2 * np.pi / N, seed=int(rng.integers(0, 1 << 30)))
+        if rng.random() < 0.15 and len(x):
+            # a carrier on top (anything from buried in the noise to 20 dB above the signal), sometimes only on
+            # a stretch: drives the metric above the candidate threshold over long runs
+            amp = float(np.sqrt(np.mean(np.abs(core) ** 2)) * 10 ** rng.uniform(-2, 1))
+            a, b = (0, len(x)) if rng.random() < 0.5 else sorted(rng.integers(0, len(x), 2).tolist())
+            x[a:b] += (amp * np.exp(2j * np.pi * rng.uniform(-0.5, 0.5) * np.arange(b - a))).astype(np.complex64)
+            desc["carrier"] = [amp, int(a), int(b)]
         taps = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK, _abi.TAP_RX_PACKETS)
         mask = 0
         for t in taps:
@@ -62,7 +69,15 @@ while time.time() < t_end:
         ro = orc.rx(cfg, x, mask)
         eng.set_taps(*taps)
         pk = eng.rx(x)
-        assert eng.tap(_abi.TAP_RX_PEAKS).tolist() == ro.tap(_abi.TAP_RX_PEAKS).tolist(), "peaks"
+        pg, po = eng.tap(_abi.TAP_RX_PEAKS).tolist(), ro.tap(_abi.TAP_RX_PEAKS).tolist()
+        if pg != po:
+            u = ro.tap(_abi.TAP_RX_METRIC)
+            d = sorted(set(pg) ^ set(po))[:6]
+            print("peaks differ: gpu %d oracle %d; symmetric difference (first) %s" % (len(pg), len(po), d))
+            for q0 in d[:3]:
+                w = u[max(0, q0 - 6):q0 + 7]
+                print("   u around %d (in gpu: %s, in oracle: %s): %s" % (q0, q0 in pg, q0 in po, np.array2string(w, precision=7)))
+        assert pg == po, "peaks"
         assert eng.tap(_abi.TAP_RX_FRAMES).tolist() == ro.tap(_abi.TAP_RX_FRAMES).tolist(), "frames"
         assert np.array_equal(eng.tap(_abi.TAP_RX_CHAN_FILT), ro.tap(_abi.TAP_RX_CHAN_FILT)), "chan_filt"
         assert np.array_equal(eng.tap(_abi.TAP_RX_METRIC), ro.tap(_abi.TAP_RX_METRIC)), "metric"
@@ -76,7 +91,10 @@ while time.time() < t_end:
             a, b = ro.tap(tap), eng.tap(tap)
             assert a.shape == b.shape, "fft shape"
             if a.size:
-                worst = float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a))))
+                # float32 transforms: the rounding floor of every bin scales with the symbol's largest bin
+                # (a carrier 20 dB above the signal lifts it everywhere)
+                scale = np.maximum(1.0, np.abs(a).max(axis=1, keepdims=True))
+                worst = float(np.max(np.abs(a - b) / scale))
                 assert worst <= 1e-5, "fft tol %g" % worst
         if pk != ro.packets or eng.tap(_abi.TAP_RX_PACKETS).tobytes() != ro.tap(_abi.TAP_RX_PACKETS).tobytes():
             # tolerate only differences confined to CRC-failed packets of the same count and lengths
