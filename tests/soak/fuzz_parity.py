@@ -34,7 +34,7 @@ while time.time() < t_end:
     pay = make_payloads(npkt, sizes, seed=int(rng.integers(0, 1 << 30)))
     lead = int(rng.integers(0, 3 * N + 50))
     tail = int(rng.integers(0, 4 * N + 2 * CP))
-    snr = float(rng.choice([12.0, 20.0, 30.0, 40.0, 60.0]))
+    snr = float(rng.choice([12.0, 20.0, 30.0, 40.0, 60.0, 80.0, 100.0]))
     cfo = float(rng.choice([0.0, 0.0, 0.03, -0.2, 0.45, 1.3, -3.2]))
     desc = dict(N=N, occ=occ, CP=CP, mod=mod, carriers=carriers, npkt=npkt, sizes=sizes.tolist(), lead=lead, tail=tail, snr=snr, cfo=cfo)
     try:
@@ -52,6 +52,12 @@ while time.time() < t_end:
         assert len(iq_g) == len(iq_o) and (len(iq_o) == 0 or np.abs(iq_g - iq_o).max() < 1e-5), "tx iq"
         # channel + RX
         x = np.concatenate([np.zeros(lead, np.complex64), iq_o, np.zeros(tail, np.complex64)])
+        if rng.random() < 0.3 and len(iq_o) > 4 * (N + CP):
+            # a silent gap cut into the burst at a symbol boundary (energy drops by the full SNR inside a tile)
+            L_ = N + CP
+            cut = lead + int(rng.integers(1, len(iq_o) // L_)) * L_
+            x = np.concatenate([x[:cut], np.zeros(int(rng.integers(1, 6000)), np.complex64), x[cut:]])
+            desc["gap_at"] = cut
         core = iq_o if len(iq_o) else np.ones(1, np.complex64)
         sigma = float(np.sqrt(np.mean(np.abs(core) ** 2) / 10 ** (snr / 10)))
         orc.channel(x, sigma=sigma, cfo=cfo * 2 * np.pi / N, seed=int(rng.integers(0, 1 << 30)))
