@@ -568,8 +568,18 @@ __global__ void k_chain_resolve(const FrameResult* __restrict__ res, uint32_t nf
     if (pre[f]) invalid[f] = 1;
   unsigned int n = *count;
   if (n > cap) {
-    atomicOr(overflow, 2u);
-    n = cap;
+    // more chain heads than the list holds (a detector set to fire on noise): walk every frame in order instead
+    int64_t cover = -1;
+    for (uint32_t f = 0; f < nframes; f++) {
+      if ((int64_t)f <= cover) continue;
+      if (f < npre && pre[f]) continue;
+      const uint32_t e = res[f].end_frame;
+      if (e > f) {
+        for (uint32_t g = f + 1; g <= e && g < nframes; g++) invalid[g] = 1;
+        cover = (int64_t)e;
+      }
+    }
+    return;
   }
   for (unsigned int i = 1; i < n; i++) {  // insertion sort
     const uint32_t v = list[i];

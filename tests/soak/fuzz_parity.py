@@ -25,10 +25,19 @@ while time.time() < t_end:
     carriers = None
     if N == 512 and occ == 200 and rng.random() < 0.5:
         carriers = maps[int(rng.integers(0, len(maps)))][:50]
+    pad_usrp = bool(rng.random() < 0.2)
     try:
-        cfg = make_cfg(mod, N, occ, CP, carriers=carriers)
+        cfg = make_cfg(mod, N, occ, CP, carriers=carriers, pad_for_usrp=pad_usrp)
     except ValueError:
         continue
+    # detector / sampler parameters away from their defaults now and then
+    cfg.sampler_timeout = int(rng.choice([1000, 1000, 1000, 7, 2]))
+    if rng.random() < 0.25:
+        cfg.peak_rise, cfg.peak_fall = float(rng.choice([0.1, 0.3, 0.5])), float(rng.choice([0.1, 0.2, 0.4]))
+    if rng.random() < 0.2:
+        cfg.peak_alpha = float(rng.choice([0.01, 0.0003]))
+    if rng.random() < 0.2:
+        cfg.max_fft_shift_len = int(rng.choice([1, 2, 8]))
     npkt = int(rng.integers(1, 12))
     sizes = rng.integers(0, min(4091, 40 * N), npkt)
     pay = make_payloads(npkt, sizes, seed=int(rng.integers(0, 1 << 30)))
@@ -36,7 +45,9 @@ while time.time() < t_end:
     tail = int(rng.integers(0, 4 * N + 2 * CP))
     snr = float(rng.choice([12.0, 20.0, 30.0, 40.0, 60.0, 80.0, 100.0]))
     cfo = float(rng.choice([0.0, 0.0, 0.03, -0.2, 0.45, 1.3, -3.2]))
-    desc = dict(N=N, occ=occ, CP=CP, mod=mod, carriers=carriers, npkt=npkt, sizes=sizes.tolist(), lead=lead, tail=tail, snr=snr, cfo=cfo)
+    desc = dict(N=N, occ=occ, CP=CP, mod=mod, carriers=carriers, npkt=npkt, sizes=sizes.tolist(), lead=lead, tail=tail, snr=snr, cfo=cfo,
+                pad=pad_usrp, timeout=int(cfg.sampler_timeout), rise=float(cfg.peak_rise), fall=float(cfg.peak_fall),
+                alpha=float(cfg.peak_alpha), shift=int(cfg.max_fft_shift_len))
     try:
         eng = engine.Engine(cfg=cfg)
     except ValueError:
@@ -44,7 +55,16 @@ while time.time() < t_end:
     ncase += 1
     try:
         # TX
-        iq_o, freq_o, framed_o = orc.tx(cfg, pay, want_taps=True)
+        try:
+            iq_o, freq_o, framed_o = orc.tx(cfg, pay, want_taps=True)
+        except ValueError:
+            # an illegal batch (USRP padding pushes a maximum-length packet past the whitening mask): the
+            # engine must refuse it the same way
+            try:
+                eng.tx(pay)
+                raise AssertionError("engine accepted a batch the oracle refuses")
+            except ValueError:
+                continue
         assert eng.make_packets(pay) == framed_o, "framed packets"
         eng.set_taps(_abi.TAP_TX_FREQ)
         iq_g = eng.tx(pay)
@@ -110,9 +130,9 @@ while time.time() < t_end:
             print("note: CRC-failed payload bits differ (slicer boundary)", json.dumps(desc))
         for k in ("headers_ok", "packets", "crc_ok", "chained_frames"):
             assert eng.last_stats[k] == ro.stats[k], k
-    except AssertionError as e:
+    except (AssertionError, engine.EngineError, ValueError) as e:
         nbad += 1
-        print("MISMATCH [%s]" % e, json.dumps(desc), flush=True)
+        print("MISMATCH [%s]" % (e if isinstance(e, AssertionError) else "error " + str(e)[:80]), json.dumps(desc), flush=True)
     finally:
         eng.close()
 print("fuzz: %d cases, %d mismatches, seed %d" % (ncase, nbad, seed))
