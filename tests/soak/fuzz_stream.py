@@ -32,10 +32,15 @@ while time.time() < t_end:
         k += n
     iq = np.concatenate(parts)
     core = parts[1]
-    snr = float(rng.choice([15.0, 25.0, 30.0, 40.0]))
+    snr = float(rng.choice([15.0, 25.0, 30.0, 40.0, 60.0, 80.0]))
     cfo = float(rng.choice([0.0, 0.05, -0.3, 1.2]))
     orc.channel(iq, sigma=float(np.sqrt(np.mean(np.abs(core) ** 2) / 10 ** (snr / 10))), cfo=cfo * 2 * np.pi / N,
                 seed=int(rng.integers(0, 1 << 30)))
+    if rng.random() < 0.2:
+        # a carrier over a stretch (or all) of the capture
+        amp = float(np.sqrt(np.mean(np.abs(core) ** 2)) * 10 ** rng.uniform(-1.5, 0.7))
+        a, b = (0, len(iq)) if rng.random() < 0.3 else sorted(rng.integers(0, len(iq), 2).tolist())
+        iq[a:b] += (amp * np.exp(2j * np.pi * rng.uniform(-0.5, 0.5) * np.arange(b - a))).astype(np.complex64)
     want = ofdm.ofdm_demod(opt).work(iq)
     s = ofdm.ofdm_demod(opt)
     got, pos, cuts = [], 0, []
