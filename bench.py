@@ -263,6 +263,7 @@ def main():
     g = parallel.reduce_counters(tot, device=dev)
     all_exact = parallel.reduce_counters({"packets": int(delivered_ok)}, device=dev)["packets"] == world
 
+    result_line = None
     if rank == 0:
         sym_per_s = g["symbols"] / elapsed
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
@@ -335,7 +336,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg_host, sigma, lead, tail, size, args.cpu_packets)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        result_line = json.dumps(out)
     eng.close()
     try:
         import torch.distributed as dist
@@ -343,6 +344,10 @@ def main():
             dist.destroy_process_group()
     except Exception:
         pass
+    if result_line is not None:
+        # last thing on stdout (RCCL / gloo print their own banners there too)
+        sys.stdout.flush()
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":
