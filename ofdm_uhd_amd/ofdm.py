@@ -172,6 +172,8 @@ class ofdm_demod(object):
             self._engine.set_taps(engine._abi.TAP_RX_FFT, engine._abi.TAP_RX_ACQ, engine._abi.TAP_RX_SINK)
         self.n_packets = 0
         self.n_ok = 0
+        self._streaming = False      # feed() has data or history pending
+        self.reset_stream()
         if getattr(options, "verbose", False):
             self._print_verbage()
 
@@ -181,8 +183,8 @@ class ofdm_demod(object):
     def work(self, iq):
         """Demodulate one contiguous IQ stream; fires the callback per packet and returns the
         list of (ok, payload)."""
-        if hasattr(self, "_s_tail"):
-            self.reset_stream()  # a one-shot call ends any chunked stream (and drops its NCO reference)
+        if self._streaming:
+            self.reset_stream()  # a one-shot call ends any chunked stream (and drops its carried history)
         pkts = self._engine.rx(iq)
         if self._log:
             self._write_logs()
@@ -230,12 +232,12 @@ class ofdm_demod(object):
         # the NCO idles at phase 0
         self._s_hist = [(0, 0, 0.0, 0)]
         self._engine.set_flag_history(None)
+        self._streaming = False
 
     def feed(self, iq, flush=False):
         """Demodulate the next chunk of a continuous capture; returns the packets that became final.
         ``flush=True`` (or flush()) ends the stream: everything still held back is delivered."""
-        if not hasattr(self, "_s_tail"):
-            self.reset_stream()
+        self._streaming = True
         T, span, lookback = self._stream_geometry()
         iq = np.ascontiguousarray(iq, np.complex64)
         buf = np.concatenate([self._s_tail, iq]) if len(self._s_tail) else iq
