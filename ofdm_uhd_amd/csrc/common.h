@@ -41,6 +41,18 @@ __device__ __forceinline__ c32 cmul_f(c32 a, c32 b) {
   return mk(fmaf(a.re, b.re, -(a.im * b.im)), fmaf(a.re, b.im, a.im * b.re));
 }
 
+// a(x) * b(x) mod P(x) in the reflected representation zlib uses for crc32_combine (x^0 = bit 31):
+// crc(A || B) = crc(A) * x^(8|B|) + crc(B)  (mod P) lets 64 lanes check-sum 16-byte pieces independently.
+__device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    p ^= (0u - ((a >> (31 - i)) & 1u)) & b;
+    b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+  }
+  return p;
+}
+
 // ---- wave / block scans -------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }

@@ -493,9 +493,9 @@ static int stage_batch(ofdm_handle* h, const uint8_t* payloads, const uint64_t* 
 static int launch_frame_pack(ofdm_handle* h, const uint8_t* d_payloads, int npkt, uint8_t* d_framed) {
   TxParams p = make_tx_params(h);
   h->prof.begin(OFDM_K_FRAME, h->stream);
-  hipLaunchKernelGGL(k_frame_pack, dim3((npkt + 255) / 256), dim3(256), 0, h->stream, p, d_payloads,
+  hipLaunchKernelGGL(k_frame_pack, dim3((npkt + 3) / 4), dim3(256), 0, h->stream, p, d_payloads,
                      h->d_payload_off.as<uint64_t>(), h->d_payload_len.as<uint32_t>(), h->d_framed_off.as<uint64_t>(),
-                     npkt, d_framed);
+                     npkt, d_framed, h->d_xp8.as<uint32_t>());
   h->prof.end(h->stream);
   HIPCHK(h, hipGetLastError());
   return OFDM_OK;

@@ -644,17 +644,6 @@ __global__ void __launch_bounds__(256) k_deframe_count(DeframeParams q) {
   q.key[f] = key;
 }
 
-// a(x) * b(x) mod P(x) in the reflected representation zlib uses for crc32_combine (x^0 = bit 31)
-__device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) {
-  uint32_t p = 0;
-#pragma unroll
-  for (int i = 0; i < 32; i++) {
-    p ^= (0u - ((a >> (31 - i)) & 1u)) & b;
-    b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
-  }
-  return p;
-}
-
 // One WAVE per frame: coalesced 16-byte loads of the raw message, dewhitening, CRC-32 as 64 independent
 // 16-byte CRCs per KiB combined with crc(A||B) = crc(A) * x^(8|B|) + crc(B)  (mod P), and dword-aligned
 // coalesced stores of the payload through an LDS staging line.

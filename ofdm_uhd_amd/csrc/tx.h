@@ -31,42 +31,157 @@ struct TxParams {
 };
 
 // ---------------------------------------------------------------------------------
-// make_packet, one thread per packet.
+// make_packet, one WAVE per packet (ofdm_packet_utils.py:99-143).
+//   pass 1  CRC-32 of the payload: each lane check-sums 16 bytes of every KiB, pieces combined with
+//           crc(A||B) = crc(A) x^(8|B|) + crc(B) (mod P) -- crc_multmodp and the x^(8k) table;
+//   pass 2  header | (payload | CRC big-endian | 0x55 tail and pad) XOR mask, composed a KiB at a time in an
+//           LDS line and written with coalesced, dword-aligned stores.
+// Both passes fetch the payload as coalesced ALIGNED dwords into LDS and realign there (packets start at
+// arbitrary byte offsets); a thread-per-packet version wrote 5.4x the bytes it produced (byte stores 1 035
+// bytes apart across lanes).
 // ---------------------------------------------------------------------------------
+__device__ __forceinline__ void fp_load_kib(const uint8_t* src, uint32_t c0, uint32_t len, uint32_t* line, int lane) {
+  // bytes [c0, min(c0 + 1024, len)) of src -> line[] such that byte i of the piece is byte (sh + i) of line
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src + c0);
+  const uint32_t* base = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+  const uint32_t sh = (uint32_t)(a & 3u);
+  const uint32_t nbytes = (len - c0 < 1024u) ? (len - c0) : 1024u;
+  const uint32_t ndw = (sh + nbytes + 3u) >> 2;  // <= 257: never past the dword that holds the last payload byte
+  for (uint32_t d = (uint32_t)lane; d < ndw; d += WAVE) line[d] = base[d];
+}
+// 4 payload bytes starting at piece-relative byte i (line filled by fp_load_kib with shift sh)
+__device__ __forceinline__ uint32_t fp_word(const uint32_t* line, uint32_t sh, uint32_t i) {
+  const uint32_t q = sh + i;
+  return __builtin_amdgcn_alignbyte(line[(q >> 2) + 1], line[q >> 2], q & 3u);
+}
+
 __global__ void __launch_bounds__(256) k_frame_pack(TxParams p, const uint8_t* __restrict__ payloads,
                                                      const uint64_t* __restrict__ payload_off,
                                                      const uint32_t* __restrict__ payload_len,
                                                      const uint64_t* __restrict__ framed_off, int npkt,
-                                                     uint8_t* __restrict__ framed) {
+                                                     uint8_t* __restrict__ framed, const uint32_t* __restrict__ xp8) {
   __shared__ uint32_t tab[256];
+  __shared__ __align__(16) uint32_t in_all[4][264];
+  __shared__ __align__(16) uint32_t out_all[4][264];
   tab[threadIdx.x] = p.crc_table[threadIdx.x];
   __syncthreads();
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = lane_id(), w = wave_id();
+  uint32_t* in = in_all[w];
+  uint32_t* stage = out_all[w];
+  const int k = blockIdx.x * 4 + w;
   if (k >= npkt) return;
   const uint8_t* src = payloads + payload_off[k];
   const uint32_t len = payload_len[k];
   uint8_t* out = framed + framed_off[k];
-  const uint32_t total = (uint32_t)(framed_off[k + 1] - framed_off[k]);
-  const uint32_t L = len + 4;
+  const uint32_t total = (uint32_t)(framed_off[k + 1] - framed_off[k]);  // 4 + len + 4 + 1 (+ pad)
   const uint32_t off = p.whitener_offset;
-  const uint32_t val = ((off & 0xF) << 12) | (L & 0x0FFF);  // make_header (ofdm_packet_utils.py:93-97)
-  out[0] = (uint8_t)(val >> 8);
-  out[1] = (uint8_t)val;
-  out[2] = (uint8_t)(val >> 8);
-  out[3] = (uint8_t)val;
-  uint8_t* body = out + 4;
-  uint32_t crc = 0xFFFFFFFFu;
-  for (uint32_t i = 0; i < len; i++) {
-    const uint8_t b = src[i];
-    crc = tab[(crc ^ b) & 0xFF] ^ (crc >> 8);
-    body[i] = b ^ p.mask[off + i];
+
+  // ---- pass 1: CRC-32 of the payload -----------------------------------------------------------
+  uint32_t acc = 0;
+  for (uint32_t c0 = 0; c0 < len; c0 += 1024) {
+    fp_load_kib(src, c0, len, in, lane);
+    if (lane == 0) in[263] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src + c0) & 3u);
+    const uint32_t o = c0 + 16u * (uint32_t)lane;
+    if (o < len) {
+      const uint32_t nb = (len - o < 16u) ? (len - o) : 16u;
+      uint32_t crc = 0xFFFFFFFFu;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t wd = (4u * (uint32_t)q < nb) ? fp_word(in, sh, 16u * (uint32_t)lane + 4u * (uint32_t)q) : 0u;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if ((uint32_t)(4 * q + b) < nb) crc = tab[(crc ^ (wd >> (8 * b))) & 0xFF] ^ (crc >> 8);
+      }
+      crc ^= 0xFFFFFFFFu;
+      acc ^= crc_multmodp(xp8[len - (o + nb)], crc);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  crc ^= 0xFFFFFFFFu;
-  body[len + 0] = (uint8_t)(crc >> 24) ^ p.mask[off + len + 0];  // struct.pack(">I", crc)
-  body[len + 1] = (uint8_t)(crc >> 16) ^ p.mask[off + len + 1];
-  body[len + 2] = (uint8_t)(crc >> 8) ^ p.mask[off + len + 2];
-  body[len + 3] = (uint8_t)crc ^ p.mask[off + len + 3];
-  for (uint32_t i = L; i < total - 4; i++) body[i] = 0x55 ^ p.mask[off + i];  // tail + USRP pad
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) acc ^= __shfl_xor(acc, d, WAVE);
+  const uint32_t crc32 = acc;  // crc32 of an empty payload is 0 = the empty XOR
+
+  // ---- pass 2: the framed packet, a KiB of OUTPUT at a time ---------------------------------------
+  const uint32_t L = len + 4;
+  const uint32_t val = ((off & 0xF) << 12) | (L & 0x0FFF);  // make_header (ofdm_packet_utils.py:93-97)
+  const uint32_t hdr = ((val >> 8) & 0xFF) | ((val & 0xFF) << 8) | (((val >> 8) & 0xFF) << 16) | ((val & 0xFF) << 24);
+  for (uint32_t c0 = 0; c0 < total; c0 += 1024) {
+    // output bytes [c0, c0+1024) hold body bytes [c0-4, c0+1020): fetch the payload part of that range
+    const uint32_t b0 = (c0 >= 4) ? c0 - 4 : 0;  // first body byte this round needs
+    if (b0 < len) {
+      // (load from a dword-aligned payload position so that fp_word's index math stays simple)
+      fp_load_kib(src, b0 & ~3u, len, in, lane);
+    }
+    if (lane == 0) in[263] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const uint32_t pb = b0 & ~3u;  // payload byte at piece-relative 0
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src + pb) & 3u);
+    uint32_t wds[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t qo = c0 + 16u * (uint32_t)lane + 4u * (uint32_t)q;  // output byte of this word
+      uint32_t wd = 0;
+      if (qo < total) {
+        if (qo == 0) {
+          wd = hdr;
+        } else {
+          const uint32_t i0 = qo - 4;  // body byte of the word's first byte (a multiple of 4)
+          uint32_t body;
+          if (i0 + 4 <= len) {
+            body = fp_word(in, sh, i0 - pb);
+          } else {
+            body = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const uint32_t i = i0 + (uint32_t)b;
+              uint32_t by;
+              if (i < len) by = (fp_word(in, sh, (i & ~3u) - pb) >> (8 * (i & 3u))) & 0xFF;
+              else if (i < len + 4) by = (crc32 >> (8 * (3 - (i - len)))) & 0xFF;  // struct.pack(">I", crc)
+              else by = 0x55;                                                        // tail + USRP pad
+              body |= by << (8 * b);
+            }
+          }
+          // whitening mask bytes off+i0 .. off+i0+3
+          const uint32_t mi = off + i0;
+          const uint32_t* m32 = reinterpret_cast<const uint32_t*>(p.mask);
+          uint32_t mk4;
+          if ((mi & 3u) == 0 && mi + 4 <= OFDM_MASK_LEN) {
+            mk4 = m32[mi >> 2];
+          } else {
+            mk4 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+              if (mi + (uint32_t)b < OFDM_MASK_LEN && i0 + (uint32_t)b < total - 4) mk4 |= (uint32_t)p.mask[mi + b] << (8 * b);
+          }
+          wd = body ^ mk4;
+        }
+      }
+      wds[q] = wd;
+    }
+    reinterpret_cast<uint4*>(stage)[lane] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+    if (lane == 0) stage[256] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the staging line is written
+    const uint32_t rem = (total - c0 < 1024u) ? (total - c0) : 1024u;
+    uint8_t* og = out + c0;
+    const uint32_t head0 = (4u - (uint32_t)((uintptr_t)og & 3u)) & 3u;
+    const uint32_t head = head0 < rem ? head0 : rem;
+    const uint32_t nd = (rem - head) >> 2;
+    const uint8_t* st8 = reinterpret_cast<const uint8_t*>(stage);
+    if ((uint32_t)lane < head) og[lane] = st8[lane];
+    for (uint32_t dw = (uint32_t)lane; dw < nd; dw += WAVE) {
+      const uint32_t i0 = head + 4u * dw;
+      const uint32_t w0 = stage[i0 >> 2], w1 = stage[(i0 >> 2) + 1];
+      reinterpret_cast<uint32_t*>(og + i0)[0] = __builtin_amdgcn_alignbyte(w1, w0, i0 & 3u);
+    }
+    const uint32_t tail0 = head + 4u * nd;
+    if (tail0 + (uint32_t)lane < rem) og[tail0 + lane] = st8[tail0 + lane];
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // ---------------------------------------------------------------------------------
