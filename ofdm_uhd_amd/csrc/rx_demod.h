@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(256) k_nco_phase(const uint64_t* __restrict__ 
 struct RxState {
   DevBuf x_stage, y, metric, tile_B, tile_np, tile_first, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
       partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
-      out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
+      out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, stash_peaks, stash_P, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
   std::vector<uint64_t> last_pos;  // host copy: flag sample of every packet of the last call
   // chunked streams (ofdm_rx_set_flag_history): flags settled by earlier calls replace whatever this call
@@ -786,7 +786,7 @@ struct RxState {
                      &cand_P,  &counters, &counts, &offsets,  &partial,  &peaks,       &peak_P,     &angle,
                      &step,    &inc,    &Phi,     &K,        &nsym,     &sym_base,    &res,        &raw,
                      &invalid, &chain_list, &key, &pos,      &out_payload, &out_off,  &out_len,    &out_ok,
-                     &out_pos, &inc_acc, &Phi_u, &peaks2, &peak_P2, &fstep, &pre_inv, &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
+                     &out_pos, &inc_acc, &Phi_u, &peaks2, &peak_P2, &fstep, &pre_inv, &stash_peaks, &stash_P, &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
     for (DevBuf* b : all) b->release();
   }
 };

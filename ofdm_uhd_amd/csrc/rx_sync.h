@@ -930,7 +930,13 @@ struct PeakParams {
   const uint32_t* offsets;  // exclusive scan of counts (write pass)
   uint64_t* peaks;          // [npeaks]
   c32* peak_P;              // [npeaks]
+  // count pass: the first PEAK_STASH flags of every tile are kept so that the write pass is a plain copy
+  // (k_peak_compact); a tile with more sets *stash_overflow and the state machine runs a second time
+  uint64_t* stash_peaks;    // [ntiles][PEAK_STASH]
+  c32* stash_P;             // [ntiles][PEAK_STASH]
+  unsigned int* stash_overflow;
 };
+#define PEAK_STASH 4
 
 template <bool WRITE>
 __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
@@ -990,6 +996,9 @@ __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
             if (WRITE) {
               p.peaks[wbase + nflag] = peak_ind;
               p.peak_P[wbase + nflag] = p.cand_P[peak_off];
+            } else if (nflag < PEAK_STASH) {
+              p.stash_peaks[g0 * PEAK_STASH + nflag] = peak_ind;
+              p.stash_P[g0 * PEAK_STASH + nflag] = p.cand_P[peak_off];
             }
             nflag++;
             state = 0;
@@ -1015,11 +1024,30 @@ __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
       if (WRITE) {
         p.peaks[wbase + nflag] = peak_ind;
         p.peak_P[wbase + nflag] = p.cand_P[peak_off];
+      } else if (nflag < PEAK_STASH) {
+        p.stash_peaks[g0 * PEAK_STASH + nflag] = peak_ind;
+        p.stash_P[g0 * PEAK_STASH + nflag] = p.cand_P[peak_off];
       }
       nflag++;
     }
   }
-  if (!WRITE) p.counts[g0] = nflag;
+  if (!WRITE) {
+    p.counts[g0] = nflag;
+    if (nflag > PEAK_STASH) atomicOr(p.stash_overflow, 1u);
+  }
+}
+
+// write pass when no tile raised more than PEAK_STASH flags: copy the stashed flags to their scanned places
+__global__ void __launch_bounds__(256) k_peak_compact(PeakParams p) {
+  const uint64_t g0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g0 >= p.ntiles) return;
+  const uint32_t n = p.counts[g0];
+  if (n == 0) return;
+  const uint32_t wbase = p.offsets[g0];
+  for (uint32_t i = 0; i < n && i < PEAK_STASH; i++) {
+    p.peaks[wbase + i] = p.stash_peaks[g0 * PEAK_STASH + i];
+    p.peak_P[wbase + i] = p.stash_P[g0 * PEAK_STASH + i];
+  }
 }
 
 // ---------------------------------------------------------------------------------
