@@ -322,7 +322,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           c32 rot = mk((float)r.re, (float)r.im);
-          if (t + m * T == N - 1) rot = mk((float)Rflag.re, (float)Rflag.im);
+          if (tl + m * T == N - 1) rot = mk((float)Rflag.re, (float)Rflag.im);
           e[m] = cmul(e[m], rot);
           r = dmul(r, RTp);
         }
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
         // two flags closer than one FFT length: look every sample's segment up
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-          const uint64_t n = s00 + (uint64_t)(t + m * T);
+          const uint64_t n = s00 + (uint64_t)(tl + m * T);  // (tl: not hoisted out of the symbol loop and spilled)
           int64_t i = (int64_t)j;
           while (i >= 0 && q.peaks[i] > n) i--;
           double ph = 0.0;
