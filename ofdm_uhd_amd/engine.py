@@ -58,6 +58,7 @@ class Engine(object):
         self.L = self.N + self.CP
         self.occ = cfg.occupied_tones
         self.last_stats = {}
+        self._rx_sense_cfg = None
 
     # -- plumbing ---------------------------------------------------------------
     def close(self):
@@ -320,6 +321,8 @@ class Engine(object):
         bodies and the means are large for long streams: leave them on the device with
         want_msgs/want_mean=False when only the decisions are needed."""
         sc = self._rx_sense_cfg
+        if sc is None:
+            raise ValueError("set_rx_sense() has not been called")
         nm, nd = self.sense_count(sc, nsamples)
         msgs, mean, bits, hexs = self._sense_outputs(sc, nm if want_msgs else 0, nd)
         onm, ond = C.c_uint64(0), C.c_uint64(0)
