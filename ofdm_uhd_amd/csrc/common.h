@@ -149,6 +149,38 @@ __device__ __forceinline__ float det_atan2f(float y, float x) {
   return (y < 0.0f) ? -r : r;
 }
 
+// ---- sin / cos, bit-reproducible (same plain IEEE operations as the CPU restatement) ---------------
+// float32 argument of any size the receiver produces (|x| < ~1e6): reduction by multiples of pi/2 in float64
+// (two-part pi/2), Cephes sinf / cosf polynomials on [-pi/4, pi/4]; <= 2 ulp.
+__device__ __forceinline__ void det_sincosf(float x, float* sn, float* cs) {
+  const double xd = (double)x;
+  const double kd = rint(xd * 0.63661977236758134308);
+  double yd = fma(-kd, 1.57079632673412561417e+00, xd);
+  yd = fma(-kd, 6.07710050650619224932e-11, yd);
+  const float y = (float)yd;
+  const int q = (int)kd & 3;
+  const float z = y * y;
+  float ps = -1.9515295891e-4f;
+  ps = ps * z + 8.3321608736e-3f;
+  ps = ps * z - 1.6666654611e-1f;
+  ps = ps * z;
+  ps = ps * y + y;
+  float pc = 2.443315711809948e-5f;
+  pc = pc * z - 1.388731625493765e-3f;
+  pc = pc * z + 4.166664568298827e-2f;
+  pc = pc * z;
+  pc = pc * z - 0.5f * z;
+  pc = pc + 1.0f;
+  float s_ = (q & 1) ? pc : ps;
+  float c_ = (q & 1) ? -ps : pc;
+  if (q & 2) {
+    s_ = -s_;
+    c_ = -c_;
+  }
+  *sn = s_;
+  *cs = c_;
+}
+
 // ---- misc -----------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t pad_symbol_hash(uint64_t seed, uint64_t pkt, uint64_t slot,
                                                              uint32_t arity) {

@@ -57,7 +57,8 @@ struct ofdm_handle {
   std::string err;
 
   // constant tables
-  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_taps, d_ks, d_smap, d_kd, d_xp8;
+  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_Hf, d_twF, d_ks, d_smap, d_kd, d_xp8;
+  int filtF = 0;  // transform length of the channel filter (sync_filter_F)
 
   // TX workspaces
   DevBuf d_payloads, d_payload_off, d_payload_len, d_framed, d_framed_off, d_sym_off, d_sym_pkt, d_iq_stage,
@@ -270,9 +271,30 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
     for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
     crc[i] = c;
   }
-  // taps padded with zeros to a multiple of 8 (fmaf(0, x, acc) == acc)
-  std::vector<float> taps((cfg->ntaps + 7) / 8 * 8 + 8, 0.0f);
-  for (uint32_t i = 0; i < cfg->ntaps; i++) taps[i] = cfg->taps[i];
+  // channel filter in the frequency domain, the way gr_fft_filter_ccc holds its taps: the F-point transform of
+  // the zero-padded taps, scaled by 1/F (the inverse transform is unnormalised).  Computed in float64 and rounded
+  // once; the oracle computes the same sums in the same order.
+  h->filtF = sync_filter_F((int)cfg->ntaps);
+  std::vector<c32> Hf(h->filtF), twF(h->filtF);
+  {
+    const int F = h->filtF;
+    std::vector<double> cs(F), sn(F);
+    for (int m = 0; m < F; m++) {
+      const double a = -2.0 * M_PI * (double)m / (double)F;
+      cs[m] = cos(a);
+      sn[m] = sin(a);
+      twF[m] = c32{(float)cs[m], (float)sn[m]};
+    }
+    for (int k = 0; k < F; k++) {
+      double re = 0.0, im = 0.0;
+      for (int n = 0; n < (int)cfg->ntaps; n++) {
+        const int idx = (int)(((long long)k * n) % F);
+        re = re + (double)cfg->taps[n] * cs[idx];
+        im = im + (double)cfg->taps[n] * sn[idx];
+      }
+      Hf[k] = c32{(float)(re / (double)F), (float)(im / (double)F)};
+    }
+  }
   // known_phase_diff of digital_ofdm_frame_acquisition's ctor
   std::vector<float> kd(occ, 0.0f);
   for (int i = 0; i + 2 < occ; i += 2) {
@@ -296,7 +318,8 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
     }
     HIPCHK(h, upload(h->d_xp8, xp8.data(), xp8.size()));
   }
-  HIPCHK(h, upload(h->d_taps, taps.data(), taps.size()));
+  HIPCHK(h, upload(h->d_Hf, Hf.data(), Hf.size()));
+  HIPCHK(h, upload(h->d_twF, twF.data(), twF.size()));
   HIPCHK(h, upload(h->d_ks, reinterpret_cast<const c32*>(cfg->known_symbol), (size_t)occ));
   HIPCHK(h, upload(h->d_kd, kd.data(), kd.size()));
   return OFDM_OK;
@@ -330,7 +353,7 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
   if (!h) return;
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   DevBuf* bufs[] = {&h->d_const,    &h->d_preamble,    &h->d_tw,          &h->d_bin2car, &h->d_mask,
-                    &h->d_crc,      &h->d_taps,        &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
+                    &h->d_crc,      &h->d_Hf,   &h->d_twF,     &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
                     &h->d_payloads, &h->d_payload_off, &h->d_payload_len, &h->d_framed,  &h->d_framed_off,
                     &h->d_sym_off,  &h->d_sym_pkt,     &h->d_iq_stage,    &h->d_freq_tap};
   for (DevBuf* b : bufs) b->release();

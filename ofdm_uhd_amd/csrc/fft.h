@@ -26,6 +26,20 @@ __host__ __device__ constexpr int fft_lds_bytes(int n) { return fft_lds_bufs(n) 
 
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
 
+// Synchronisation of the N/8 threads of one transform.  Up to N = 512 they sit inside ONE wavefront: DS
+// instructions of a wave execute in issue order, so an exchange needs no s_barrier -- only the compiler must
+// keep the LDS accesses on their side of the exchange (wavefront-scope fences + the scheduling barrier).
+struct FftWaveSync {
+  __device__ __forceinline__ void operator()() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
+struct FftBlockSync {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+
 template <bool INV>
 __device__ __forceinline__ c32 mul_mi(c32 a) {  // forward: a * (-i) ; inverse: a * (+i)
   return INV ? mk(-a.im, a.re) : mk(a.im, -a.re);
@@ -193,5 +207,46 @@ __device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __
     fft_pass<4096, 8, 64, INV, false, false, true>(e, t, A, A, tw, sync);
     sync();
     fft_pass<4096, 8, 512, INV, false, true>(e, t, A, nullptr, tw);
+  }
+}
+
+// The same transform (same butterflies, same twiddles, same results bit for bit) in ONE LDS buffer of
+// fft_lds_points(N) points for every N: middle passes run in place.  sync() is also called on entry, so that
+// back-to-back transforms in the same scratch are safe when the N/8 threads span more than one wave.
+template <int N, bool INV, typename SyncFn>
+__device__ __forceinline__ void fft_run1(c32 e[8], int t, c32* A, const c32* __restrict__ tw, SyncFn sync) {
+  sync();
+  if constexpr (N == 64) {
+    fft_pass<64, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<64, 8, 8, INV, false, true>(e, t, A, nullptr, tw);
+  } else if constexpr (N == 128) {
+    fft_pass<128, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<128, 8, 2, INV, false, false, true>(e, t, A, A, tw, sync);
+    sync();
+    fft_pass<128, 8, 16, INV, false, true>(e, t, A, nullptr, tw);
+  } else if constexpr (N == 256) {
+    fft_pass<256, 4, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<256, 8, 4, INV, false, false, true>(e, t, A, A, tw, sync);
+    sync();
+    fft_pass<256, 8, 32, INV, false, true>(e, t, A, nullptr, tw);
+  } else if constexpr (N == 512) {
+    fft_pass<512, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<512, 8, 8, INV, false, false, true>(e, t, A, A, tw, sync);
+    sync();
+    fft_pass<512, 8, 64, INV, false, true>(e, t, A, nullptr, tw);
+  } else if constexpr (N == 1024) {
+    fft_pass<1024, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    sync();
+    fft_pass<1024, 8, 2, INV, false, false, true>(e, t, A, A, tw, sync);
+    sync();
+    fft_pass<1024, 8, 16, INV, false, false, true>(e, t, A, A, tw, sync);
+    sync();
+    fft_pass<1024, 8, 128, INV, false, true>(e, t, A, nullptr, tw);
+  } else {
+    fft_run<N, INV>(e, t, A, tw, sync);  // N >= 2048 already works in one buffer
   }
 }

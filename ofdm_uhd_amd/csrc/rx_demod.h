@@ -208,11 +208,37 @@ __device__ __forceinline__ dc dmul(dc a, dc b) {
   r.im = a.re * b.im + a.im * b.re;
   return r;
 }
+// exp(j ph) for the NCO, bit-reproducible: wrap to [-pi, pi], reduce by multiples of pi/2 (two-part constant),
+// fdlibm kernel polynomials with explicit fma() -- the CPU restatement evaluates the same operations.
 __device__ __noinline__ dc dexpj(double ph) {
   ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
-  dc r;
-  sincos(ph, &r.im, &r.re);
-  return r;
+  const double kd = rint(ph * 0.63661977236758134308);
+  double y = fma(-kd, 1.57079632673412561417e+00, ph);
+  y = fma(-kd, 6.07710050650619224932e-11, y);
+  const int q = (int)kd & 3;
+  const double z = y * y;
+  double r = 1.58969099521155010221e-10;
+  r = fma(z, r, -2.50507602534068634195e-08);
+  r = fma(z, r, 2.75573137070700676789e-06);
+  r = fma(z, r, -1.98412698298579493134e-04);
+  r = fma(z, r, 8.33333333332248946124e-03);
+  r = fma(z, r, -1.66666666666666324348e-01);
+  const double sn = fma(y * z, r, y);
+  double c = -1.13596475577881948265e-11;
+  c = fma(z, c, 2.08757232129817482790e-09);
+  c = fma(z, c, -2.75573143513906633035e-07);
+  c = fma(z, c, 2.48015872894767294178e-05);
+  c = fma(z, c, -1.38888888888741095749e-03);
+  c = fma(z, c, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, c, fma(-0.5, z, 1.0));
+  dc o;
+  o.im = (q & 1) ? cs : sn;
+  o.re = (q & 1) ? -sn : cs;
+  if (q & 2) {
+    o.im = -o.im;
+    o.re = -o.re;
+  }
+  return o;
 }
 
 #ifndef DEMOD_WAVES
@@ -391,7 +417,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
         {
           const double a = -6.283185307179586476925 * (double)coarse * (double)q.CP / (double)N * 1.0;
           const float af = (float)a;
-          const c32 comp = mk(cosf(af), sinf(af));
+          c32 comp;
+          det_sincosf(af, &comp.im, &comp.re);
           for (int i = 2 * t; i < q.occ; i += 2 * T) {
             const int yi = i + q.zl + coarse;
             const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
@@ -411,15 +438,15 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       }
       c32 comp;
       {
-        // coarse == 0 (the common case): a = -0.0, cos = 1, sin = -0 exactly -- skip the transcendental
+        // coarse == 0 (the common case): a = -0.0, for which det_sincosf gives (+0, 1) -- skip the evaluation
         if (coarse != 0) {
           const double a = -6.283185307179586476925 * (double)coarse * (double)q.CP / (double)N * (double)phase_count;
           const float af = (float)a;
           float sn, cs;
-          sincosf(af, &sn, &cs);
+          det_sincosf(af, &sn, &cs);
           comp = mk(cs, sn);
         } else {
-          comp = mk(1.0f, -0.0f);
+          comp = mk(1.0f, 0.0f);
         }
         phase_count++;
         if (phase_count == 1000) phase_count = 1;
@@ -441,7 +468,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       }
       // demapper
       c32 carrier;
-      sincosf(pll_phase, &carrier.im, &carrier.re);  // one range reduction for both
+      det_sincosf(pll_phase, &carrier.im, &carrier.re);  // gr_expj(d_phase), bit-reproducible form
       float are = 0.f, aim = 0.f;
       const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
@@ -479,7 +506,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       }
       if (q.tap_demapped && t == 0) q.tap_demapped[symb + k] = 1;
       block_sum2_f<T>(are, aim, red);
-      const float angle = atan2f(aim, are);
+      const float angle = det_atan2f(aim, are);  // arg(accumulated error), bit-reproducible form
       pll_freq = pll_freq - q.freq_gain * angle;
       pll_phase = pll_phase + pll_freq - q.phase_gain * angle;
       if (pll_phase >= 6.28318530717958647692f) pll_phase -= 6.28318530717958647692f;

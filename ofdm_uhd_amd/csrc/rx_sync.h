@@ -26,12 +26,12 @@
 // average, whose rounding in the reference is of the same order.
 #pragma once
 #include "common.h"
+#include "fft.h"
 
 #define SYNC_THREADS 256
 #define SYNC_V 8                            // consecutive samples per thread
 #define SYNC_TILE (SYNC_THREADS * SYNC_V)   // 2048 samples per tile
 #define SYNC_GUARD 1.0e-3f                  // guard band of the float32 pre-selection
-#define SYNC_MAX_TAPS OFDM_MAX_TAPS
 #define SYNC_CHUNK_C 4096                   // candidates per allocation chunk (>= SYNC_TILE)
 #define SYNC_CHUNK_P 1024                   // pieces per allocation chunk (>= SYNC_TILE / 2)
 
@@ -44,14 +44,16 @@ struct SyncPiece {
 
 struct SyncParams {
   int N, D, CP;
-  int HX;         // x history kept in LDS (padded tap count, multiple of 8)
-  int HY;         // y history (2*D + CP, multiple of 8)
+  int HY;         // y history the metric needs before a tile (2*D + CP, multiple of 8)
   int HM;         // M history (CP)
-  int ntaps_pad;  // multiple of 8
+  int F;          // channel filter: transform length of the overlap-save blocks (gr_fft_filter_ccc's choice)
+  int B;          // outputs per block = F - ntaps + 1
+  int ntm1;       // ntaps - 1 = F - B
+  int R;          // samples in the LDS ring of y (multiple of 8)
   int tiles_per_seg, nwarm;
   int exact_all;  // metric tap: evaluate every sample in fixed point
-  int ablate;     // diagnostic build only (-DSYNC_DIAG, see SYNC_ABLATE): 1 skip filter taps, 2 skip metric, 4 skip y store
-  unsigned long long* stamps;  // diagnostic build (-DSYNC_STAMPS): [wg][8] cycles per phase of wave 0
+  int ablate;     // diagnostic build only (-DSYNC_DIAG, see SYNC_ABLATE): 1 skip the filter transforms, 2 skip metric, 4 skip y store
+  unsigned long long* stamps;  // diagnostic build (-DSYNC_STAMPS): [wg][12] cycles per phase of wave 0
   uint64_t nsamples, ntiles;
   float tapcp;       // float(1/CP)
   float cand_thr;    // -max(rise, fall)
@@ -59,6 +61,8 @@ struct SyncParams {
   double decay;      // double(1.0f - alpha)
   const c32* x;
   c32* y;
+  const c32* Hf;      // [F] transform of the taps, scaled by 1/F
+  const c32* twF;     // [F] exp(-2 pi i k / F)
   float* metric_tap;  // optional [nsamples]
   // outputs
   double* tile_B;          // [ntiles] zero-init running average over the tile
@@ -74,45 +78,58 @@ struct SyncParams {
   uint64_t cand_cap;
   unsigned long long* cand_count;  // device counter
   unsigned int* overflow;          // device flag
-  float taps[SYNC_MAX_TAPS + 56];   // in the kernel-argument segment: read with scalar loads
 };
 
 __host__ __device__ inline int sync_lp(int i) { return i + (i >> 3); }
 
+// Filter geometry (host and device): gr_fft_filter_ccc sizes its transform as 2 * 2^ceil(log2(ntaps)) and
+// produces F - ntaps + 1 outputs per block; transforms shorter than 64 points are not built.
+__host__ __device__ inline int sync_filter_F(int ntaps) {
+  int p2 = 1;
+  while (p2 < ntaps) p2 <<= 1;
+  const int f = 2 * p2;
+  return f < 64 ? 64 : f;
+}
+// ring of y: the history a tile's metric looks back on, the tile, and what a round of transforms may run ahead
+__host__ __device__ inline int sync_ring_samples(int HY, int F, int B) {
+  const int bpr = SYNC_THREADS / (F / 8);
+  return (HY + SYNC_TILE + (bpr - 1) * B + F + 7) / 8 * 8;
+}
+
 struct SyncLds {
-  size_t xs, ys, mh, mt, me, ue, misc, total;
+  size_t ys, work, mt, me, ue, mh, misc, total;
 };
-// LDS diet: between the filter (B2) and the next tile's x store, everything of `xs` beyond the HX history
-// entries is dead.  The tile's M values (mt), and -- rare path -- the exact M (me) live there; the exact
-// u (ue) overlays mt, which is dead by then because the CP newest M values are saved to the small
-// persistent history mh right after the moving average.  At C2 this brings a workgroup from 72 KB to
-// 46 KB = three workgroups per CU.  When CP is too large for me to fit behind mt it gets its own region.
-__host__ __device__ inline SyncLds sync_lds_layout(int HX, int HY, int HM, int CP) {
+// LDS: the ring of filtered samples | a work area that is the transforms' scratch during the filter phase and
+// holds the tile's M values (mt; later the exact u, ue) and -- rare path -- the exact M (me) during the metric
+// phase | the CP newest M values of the previous tile (mh) | scan / vote scratch.
+__host__ __device__ inline SyncLds sync_lds_layout(int R, int HM, int CP) {
   SyncLds l;
   size_t o = 0;
-  l.xs = o;
-  const size_t xs_bytes = (size_t)(sync_lp(HX + SYNC_TILE) + 2) * sizeof(c32);
-  o += xs_bytes;
   l.ys = o;
-  o += (size_t)(sync_lp(HY + SYNC_TILE) + 2) * sizeof(c32);
+  o += (size_t)(sync_lp(R) + 2) * sizeof(c32);
+  o = (o + 15) & ~(size_t)15;
+  l.work = o;
+  l.mt = o;  // M of the tile; later: exact u over [amin, bmax] (needs SYNC_TILE + 8 floats)
+  l.ue = o;
+  const size_t mt_bytes = ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  const size_t me_bytes = ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
+  l.me = o + mt_bytes;  // exact M over [amin-CP+1, bmax]
+  const size_t fft_bytes = (size_t)SYNC_THREADS * 9 * sizeof(c32);  // (256 / (F/8)) transforms x (F + F/8) points, any F
+  const size_t work_bytes = mt_bytes + me_bytes > fft_bytes ? mt_bytes + me_bytes : fft_bytes;
+  o += work_bytes;
   l.mh = o;  // M history: the CP values before the tile
   o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
-  // scratch inside xs, 16-byte aligned, after the x history
-  size_t so = ((size_t)(sync_lp(HX) + 1) * sizeof(c32) + 15) & ~(size_t)15;
-  l.mt = so;  // M of the tile; later: exact u over [amin, bmax] (needs SYNC_TILE + 8 floats)
-  l.ue = so;
-  so += ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
-  const size_t me_bytes = ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
-  if (so + me_bytes <= xs_bytes) {
-    l.me = so;  // exact M over [amin-CP+1, bmax]
-  } else {
-    l.me = o;
-    o += me_bytes;
-  }
   l.misc = o;
   o += 1024;
   l.total = o;
   return l;
+}
+
+// slot of a ring-relative position s in (-R, 2R)
+__device__ __forceinline__ int ring_wrap(int s, int R) {
+  s += (s < 0) ? R : 0;
+  s -= (s >= R) ? R : 0;
+  return s;
 }
 
 // affine map a -> A*a + b, composition "first f then g"
@@ -264,15 +281,15 @@ __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scra
 // does not weigh on the register allocation of the streaming loop.
 // ---------------------------------------------------------------------------------
 __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* ue, c32* gP, float* gU, long long* sc_i64, int amin,
-                                              int bmax, int D, int CP, int HY, int64_t t0s, int64_t qvalid, int64_t mvalid,
+                                              int bmax, int D, int CP, int rbase, int R, int64_t t0s, int64_t qvalid, int64_t mvalid,
                                               float tapcp) {
   const int tid = threadIdx.x;
 #define QTERM(m)                                                                   \
   ([&]() -> Q3 {                                                                   \
     Q3 q_ = {0, 0, 0};                                                             \
     if (t0s + (int64_t)(m) >= qvalid) {                                            \
-      const c32 a_ = ys[sync_lp(HY + (m))];                                        \
-      const c32 d_ = ys[sync_lp(HY + (m) - D)];                                    \
+      const c32 a_ = ys[sync_lp(ring_wrap(rbase + (m), R))];                       \
+      const c32 d_ = ys[sync_lp(ring_wrap(rbase + (m) - D, R))];                   \
       const c32 c_ = cmul_conj(a_, d_);                                            \
       q_.pr = q40_clamped(c_.re);                                                  \
       q_.pi = q40_clamped(c_.im);                                                  \
@@ -357,9 +374,6 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 #define STAMP(i) do { } while (0)
 #endif
 
-#ifndef SYNC_PREFETCH
-#define SYNC_PREFETCH 1
-#endif
 // Phase ablation for timing experiments exists only in the diagnostic build (make diag ->
 // libofdm_hip_diag.so, selected with OFDM_HIP_LIB); the product library always runs every phase.
 #ifdef SYNC_DIAG
@@ -367,10 +381,16 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 #else
 #define SYNC_ABLATE(p, bit) 0
 #endif
-// U: tap blocks per filter iteration.  W: workgroups per CU the register allocation aims at -- 3 when the
-// LDS footprint allows three (<= 53 KB, e.g. C2), else 2 (long symbols: the y history alone is N+CP samples),
-// where the larger register budget avoids the spills the 3-workgroup build accepts.
-template <int U, int W>
+// F: transform length of the channel filter's overlap-save blocks.  W: workgroups per CU the register allocation
+// aims at -- 3 when the LDS footprint allows three, else 2.
+//
+// Channel filter = gr_fft_filter_ccc(1, taps) (ofdm_receiver.py~:76,131) the way GNU Radio runs it: blocks of
+// B = F - ntaps + 1 outputs on the grid b*B of the stream; block b transforms the F samples x[b*B - (ntaps-1) ..
+// b*B + B), multiplies by the transformed taps (scaled 1/F) and keeps the last B points of the inverse
+// transform.  One block = F/8 threads (one wave at F = 512), 8 points per thread in registers, exchanges through
+// a private LDS scratch, no workgroup barrier inside a round; a round = 256/(F/8) blocks side by side.  The
+// transform schedule is fft.h's (the oracle runs the identical schedule: y is bit-exact).
+template <int F, int W>
 __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -379,9 +399,12 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   constexpr int T = SYNC_TILE;
-  const SyncLds L = sync_lds_layout(p.HX, p.HY, p.HM, p.CP);
-  c32* xs = reinterpret_cast<c32*>(smem + L.xs);
+  constexpr int TF = F / 8;               // threads per filter block
+  constexpr int BPR = SYNC_THREADS / TF;  // filter blocks per round
+  const int R = p.R;
+  const SyncLds L = sync_lds_layout(R, p.HM, p.CP);
   c32* ys = reinterpret_cast<c32*>(smem + L.ys);
+  c32* fsc = reinterpret_cast<c32*>(smem + L.work);
   float* mh = reinterpret_cast<float*>(smem + L.mh);
   float* mt = reinterpret_cast<float*>(smem + L.mt);
   float* me = reinterpret_cast<float*>(smem + L.me);
@@ -406,164 +429,85 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   const uint64_t ws = tile_first * (uint64_t)T;
   const int64_t qvalid = warm ? (int64_t)(ws + (uint64_t)p.D) : 0;
   const int64_t mvalid = warm ? (int64_t)(ws + 2ull * (uint64_t)p.D) - 1 : 0;
-  const int D = p.D, CP = p.CP, HY = p.HY, HM = p.HM;
+  const int D = p.D, CP = p.CP, HM = p.HM;
+  const int B = p.B, ntm1 = p.ntm1;
   const float inv_cp = 1.0f / (float)CP;
 
-  // ---- segment prologue: x history from the stream, y / M history zero ---------
-  for (int i = tid; i < p.HX; i += SYNC_THREADS) {
-    const int64_t n = (int64_t)ws - (int64_t)p.HX + i;
-    c32 v = mk(0.f, 0.f);
-    if (n >= 0 && (uint64_t)n < p.nsamples) v = p.x[n];
-    xs[sync_lp(i)] = v;
-  }
-  // the per-tile slide moves [T, T+H) to [0, H): park the zero history where the first slide picks it up
-  for (int i = tid; i < HY; i += SYNC_THREADS) ys[sync_lp(i + T)] = mk(0.f, 0.f);
+  // ---- segment prologue: the ring (y before the stream start reads as zero) and the M history ----
+  for (int i = tid; i < sync_lp(R) + 2; i += SYNC_THREADS) ys[i] = mk(0.f, 0.f);
   for (int i = tid; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = 0.0f;
-  const bool x_al16 = ((uintptr_t)p.x & 15) == 0;
   const bool y_al16 = ((uintptr_t)p.y & 15) == 0;
   // weight of this thread's 8 samples in the tile summary of the detector average
   const float decay_f = (float)p.decay;
   const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
-  // LDS indices of this thread's 8 consecutive samples (HX, HY, D multiples of 8: lp(8g + r) = 9g + r)
-  float4 xpre[SYNC_V / 2];
-  bool have_pre = false;
   // current allocation chunks of this workgroup (uniform across the block)
   unsigned long long cand_base = 0, piece_base = 0;
   uint32_t cand_left = 0, piece_left = 0;
+  // filter front: first sample of the next block to transform; the ring slot of the tile's first sample
+  uint64_t fbs = (ws / (uint64_t)B) * (uint64_t)B;
+  int rbase = 0;
   __syncthreads();
 
-  for (uint64_t tile = tile_first; tile < tile_own1; tile++) {
+  for (uint64_t tile = tile_first; tile < tile_own1; tile++, rbase = (rbase + T >= R) ? rbase + T - R : rbase + T) {
     // Opaque copy of the thread index, renewed every tile: otherwise the compiler hoists every
     // tid-dependent LDS address of the loop body out of the loop and then spills them.
     int tl = tid;
     asm volatile("" : "+v"(tl));
-    const int gb = sync_lp(p.HX + SYNC_V * tl - 8);
-    const int yb = sync_lp(HY + SYNC_V * tl), yb1 = sync_lp(HY - D + SYNC_V * tl), yb2 = sync_lp(HY - 2 * D + SYNC_V * tl);
     const uint64_t t0 = tile * (uint64_t)T;
     const int64_t t0s = (int64_t)t0;
     const bool owned = tile >= tile_own0;
     const bool masked = warm && (t0s < qvalid + D);  // some sample of the tile lacks real history
 
-    // ---- 1. x tile into LDS (prefetched during the previous tile's filter when possible);
-    //         slide the y and M histories.  All hazards are covered by the barriers of the
-    //         previous iteration (k_sync).
-    if (have_pre) {
+    // ---- 1 + 2. channel filter: rounds of BPR overlap-save blocks until the tile is covered.  Ring hazards: a
+    //         round overwrites slots whose samples lie more than HY before this tile -- every read of them
+    //         happened before the last barrier of the previous iteration; the transforms' scratch overlays
+    //         mt / me / ue, which are dead by then for the same reason.
+    while (fbs < t0 + (uint64_t)T) {
+      const int g = tl / TF, t = tl % TF;
+      c32* sc = fsc + g * fft_lds_points(F);
+      const int64_t bs = (int64_t)fbs + (int64_t)g * B;  // first output sample of this thread's block
+      const int64_t x0 = bs - ntm1 + t;
+      c32 e[8];
 #pragma unroll
-      for (int r = 0; r < SYNC_V / 2; r++) {
-        const int pi = tl + r * SYNC_THREADS;  // pair index
-        const int li = sync_lp(p.HX + 2 * pi);
-        xs[li] = mk(xpre[r].x, xpre[r].y);
-        xs[li + 1] = mk(xpre[r].z, xpre[r].w);
+      for (int m = 0; m < 8; m++) {
+        const int64_t xi = x0 + m * TF;
+        e[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
       }
-    } else if (x_al16 && t0 + (uint64_t)T <= p.nsamples) {
-      const float4* src = reinterpret_cast<const float4*>(p.x + t0);
-#pragma unroll
-      for (int r = 0; r < SYNC_V / 2; r++) {
-        const int pi = tl + r * SYNC_THREADS;
-        const float4 v = src[pi];
-        const int li = sync_lp(p.HX + 2 * pi);
-        xs[li] = mk(v.x, v.y);
-        xs[li + 1] = mk(v.z, v.w);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < SYNC_V; r++) {
-        const int i = tl + r * SYNC_THREADS;
-        const uint64_t n = t0 + (uint64_t)i;
-        c32 v = mk(0.f, 0.f);
-        if (n < p.nsamples) v = p.x[n];
-        xs[sync_lp(p.HX + i)] = v;
-      }
-    }
-    if (HY <= T) {
-      for (int i = tl; i < HY; i += SYNC_THREADS) ys[sync_lp(i)] = ys[sync_lp(i + T)];
-    } else {
-      for (int off = 0; off < HY; off += T) {  // overlapping ranges: chunk by chunk
-        c32 v[SYNC_V];
-#pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tl + r * SYNC_THREADS;
-          if (i < HY && i < off + T) v[r] = ys[sync_lp(i + T)];
+      if (!SYNC_ABLATE(p, 1)) {
+        if constexpr (TF <= WAVE) {
+          fft_run1<F, false>(e, t, sc, p.twF, FftWaveSync());
+        } else {
+          fft_run1<F, false>(e, t, sc, p.twF, FftBlockSync());
         }
-        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = off + tl + r * SYNC_THREADS;
-          if (i < HY && i < off + T) ys[sync_lp(i)] = v[r];
+        for (int m = 0; m < 8; m++) e[m] = cmul(e[m], p.Hf[t + m * TF]);  // volk_32fc_x2_multiply_32fc
+        if constexpr (TF <= WAVE) {
+          fft_run1<F, true>(e, t, sc, p.twF, FftWaveSync());
+        } else {
+          fft_run1<F, true>(e, t, sc, p.twF, FftBlockSync());
         }
-        __syncthreads();
       }
-    }
-    __syncthreads();  // B1
-    STAMP(0);
-
-    // prefetch the next tile of x; its latency hides behind the filter
-    have_pre = false;
-    // (register prefetch only in the 2-workgroup build: at 168 VGPRs one of its four vectors was spilled
-    //  to scratch and back every tile -- 2.5 KB of HBM traffic per symbol for nothing; three resident
-    //  workgroups hide the load latency by themselves)
-    if (SYNC_PREFETCH && W < 3 && tile + 1 < tile_own1 && x_al16 && t0 + 2ull * T <= p.nsamples) {
-      const float4* src = reinterpret_cast<const float4*>(p.x + t0 + T);
+      const int rel0 = rbase + (int)(bs - t0s) - ntm1 + t;  // ring-relative position of transform point t
 #pragma unroll
-      for (int r = 0; r < SYNC_V / 2; r++) xpre[r] = src[tl + r * SYNC_THREADS];
-      have_pre = true;
-    }
-
-    // ---- 2. channel filter: one fmaf chain per output, taps in order ----------------
-    {
-      c32 acc[SYNC_V];
-#pragma unroll
-      for (int j = 0; j < SYNC_V; j++) acc[j] = mk(0.f, 0.f);
-      // U blocks of 8 taps per iteration.  Inside the body the sliding window is renamed by the
-      // compiler (static indices, no moves); it is re-read from LDS at the top of every iteration so
-      // that nothing but one index is carried around the loop.  The taps of an iteration sit in SGPRs.
-      int gw = gb;
-      for (int kb = 0; kb < (SYNC_ABLATE(p, 1) ? 8 * U : p.ntaps_pad); kb += 8 * U) {
-        c32 w[15];  // w[d] = x[out0 - kb - 7 + d]
-#pragma unroll
-        for (int d = 0; d < 7; d++) w[d] = xs[gw + 1 + d];
-#pragma unroll
-        for (int d = 7; d < 15; d++) w[d] = xs[gw + 9 + (d - 7)];
-        int g = gw - 9;  // group holding the next 7 older samples (index g+9 = sample 0 of the group above)
-#pragma unroll
-        for (int b = 0; b < U; b++) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const float hk = p.taps[kb + b * 8 + i];
-#pragma unroll
-            for (int j = 0; j < SYNC_V; j++) {
-              acc[j].re = fmaf(hk, w[j - i + 7].re, acc[j].re);
-              acc[j].im = fmaf(hk, w[j - i + 7].im, acc[j].im);
-            }
-          }
-          if (b + 1 < U) {
-#pragma unroll
-            for (int d = 14; d >= 8; d--) w[d] = w[d - 8];
-#pragma unroll
-            for (int d = 0; d < 7; d++) w[d] = xs[g + 1 + d];
-            w[7] = xs[g + 9];
-            g -= 9;
-          }
-        }
-        gw -= 9 * U;
+      for (int m = 0; m < 8; m++) {
+        if (t + m * TF >= ntm1) ys[sync_lp(ring_wrap(rel0 + m * TF, R))] = e[m];
       }
-#pragma unroll
-      for (int j = 0; j < SYNC_V; j++) ys[yb + j] = acc[j];
+      fbs += (uint64_t)BPR * (uint64_t)B;
     }
     STAMP(1);
-    __syncthreads();  // B2
+    __syncthreads();  // B2: the tile's y is in the ring
     STAMP(2);
-    // x history for the next tile: [T, T+HX) -> [0, HX) (disjoint, T >= HX); the rest of xs is scratch from here on
-    for (int i = tl; i < p.HX; i += SYNC_THREADS) xs[sync_lp(i)] = xs[sync_lp(i + T)];
+    const int ybs = ring_wrap(rbase + SYNC_V * tl, R);
+    const int yb = sync_lp(ybs), yb1 = sync_lp(ring_wrap(ybs - D, R)), yb2 = sync_lp(ring_wrap(ring_wrap(ybs - D, R) - D, R));
 
-    // ---- 3. y to HBM (owned tiles only), coalesced from LDS ----------------------------
+    // ---- 3. y to HBM (owned tiles only), coalesced from the ring ----------------------------
     if (owned && !SYNC_ABLATE(p, 4)) {
       if (y_al16 && t0 + (uint64_t)T <= p.nsamples) {
         float4* dst = reinterpret_cast<float4*>(p.y + t0);
 #pragma unroll
         for (int r = 0; r < SYNC_V / 2; r++) {
           const int pi = tl + r * SYNC_THREADS;
-          const int li = sync_lp(HY + 2 * pi);
+          const int li = sync_lp(ring_wrap(rbase + 2 * pi, R));
           const c32 a = ys[li], b = ys[li + 1];
           dst[pi] = make_float4(a.re, a.im, b.re, b.im);
         }
@@ -572,7 +516,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
         for (int r = 0; r < SYNC_V; r++) {
           const int i = tl + r * SYNC_THREADS;
           const uint64_t n = t0 + (uint64_t)i;
-          if (n < p.nsamples) p.y[n] = ys[sync_lp(HY + i)];
+          if (n < p.nsamples) p.y[n] = ys[sync_lp(ring_wrap(rbase + i, R))];
         }
       }
     }
@@ -600,8 +544,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
       // anchor: the window sums at the sample before the tile, summed afresh from the history
       for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
-        const c32 a = ys[sync_lp(HY + m)];
-        const c32 d1 = ys[sync_lp(HY + m - D)];
+        const int sa = ring_wrap(rbase + m, R);
+        const c32 a = ys[sync_lp(sa)];
+        const c32 d1 = ys[sync_lp(ring_wrap(sa - D, R))];
         anc.a += fmaf(a.re, d1.re, a.im * d1.im);
         anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
         anc.c += fmaf(a.re, a.re, a.im * a.im);
@@ -633,8 +578,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
       for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
         if (t0s + m >= qvalid) {
-          const c32 a = ys[sync_lp(HY + m)];
-          const c32 d1 = ys[sync_lp(HY + m - D)];
+          const int sa = ring_wrap(rbase + m, R);
+          const c32 a = ys[sync_lp(sa)];
+          const c32 d1 = ys[sync_lp(ring_wrap(sa - D, R))];
           anc.a += fmaf(a.re, d1.re, a.im * d1.im);
           anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
           anc.c += fmaf(a.re, a.re, a.im * a.im);
@@ -690,7 +636,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     // the CP newest M values become the next tile's history (every thread has done its reads of mh
     // and mt before B5; mt is free from here on)
     for (int i = tl; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = mt[sync_lp(T - HM + i)];
-    if (!owned) continue;  // warm-up tile: only the histories matter
+    if (!owned) {  // warm-up tile: only the histories matter
+      __syncthreads();  // (the next tile's transforms overwrite mt, which the copy above reads)
+      continue;
+    }
 
     float u[SYNC_V];
 #pragma unroll
@@ -766,7 +715,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     cand_base += (unsigned long long)rlen;
     cand_left -= (uint32_t)rlen;
     if (fits) {
-      sync_exact_range(ys, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, HY, t0s, qvalid, mvalid,
+      sync_exact_range(ys, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, rbase, R, t0s, qvalid, mvalid,
                        p.tapcp);
     } else {
       for (int i = tl; i < rlen; i += SYNC_THREADS) ue[i] = -1.0f;  // nothing can be stored: no candidates

@@ -297,59 +297,258 @@ int orc_carrier_map(int occ, int container, const char *carriers, int *map, int 
 
 /* ------------------------------------------------------------------------ */
 /* FFT: gr_fft_vcc over FFTW3f (ofdm.py:112, ofdm_receiver.py~:126): unnormalised
- * DFT, float32.  Radix-2 decimation in time, twiddles rounded from float64.  */
+ * DFT, float32.  FFTW's codelets and plan are not reproducible by anyone else, so
+ * the NORMATIVE transform of this code base is fixed here, operation by operation,
+ * and the HIP engine (csrc/fft.h) evaluates the identical expression DAG -- every
+ * transform output is therefore bit-exact between the two:
+ *   Stockham autosort, passes of radix 8 preceded by ONE pass of radix 2 or 4 when
+ *   log2(n) is not a multiple of 3; pass with radix R over sub-transforms of length
+ *   LS (LS = product of the earlier radices): butterfly j < n/R takes
+ *   v[q] = src[j + q*n/R], multiplies v[q] (q >= 1) by tw[(j % LS) * q * n/(LS*R)]
+ *   with ONE fused multiply-add per part (fmaf(a.re,w.re,-(a.im*w.im)),
+ *   fmaf(a.re,w.im,a.im*w.re)), applies the radix-R kernel below (plain float32
+ *   adds; the 1/sqrt(2) rotations are two products each) and stores
+ *   dst[(j - j%LS)*R + j%LS + r*LS] = v[r].  Twiddles: (float)cos / (float)sin of
+ *   -2 pi k / n evaluated in float64; the inverse transform conjugates them.      */
 /* ------------------------------------------------------------------------ */
 typedef struct {
-  int n, logn;
-  float *wr, *wi; /* exp(-2 pi i k / n), k < n/2 */
-  int *rev;
+  int n;
+  ofdm_c32 *tw;  /* exp(-2 pi i k / n), k < n */
+  ofdm_c32 *buf; /* scratch, n points */
 } fft_plan;
 
 static void fft_plan_init(fft_plan *p, int n) {
   p->n = n;
-  p->logn = ilog2_ceil((unsigned)n);
-  p->wr = (float *)malloc(sizeof(float) * (size_t)n / 2);
-  p->wi = (float *)malloc(sizeof(float) * (size_t)n / 2);
-  p->rev = (int *)malloc(sizeof(int) * (size_t)n);
-  for (int k = 0; k < n / 2; k++) {
+  p->tw = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)n);
+  p->buf = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)n);
+  for (int k = 0; k < n; k++) {
     double a = -2.0 * M_PI * (double)k / (double)n;
-    p->wr[k] = (float)cos(a);
-    p->wi[k] = (float)sin(a);
-  }
-  for (int i = 0; i < n; i++) {
-    int r = 0;
-    for (int b = 0; b < p->logn; b++)
-      if (i & (1 << b)) r |= 1 << (p->logn - 1 - b);
-    p->rev[i] = r;
+    p->tw[k] = c32((float)cos(a), (float)sin(a));
   }
 }
 static void fft_plan_free(fft_plan *p) {
-  free(p->wr);
-  free(p->wi);
-  free(p->rev);
+  free(p->tw);
+  free(p->buf);
 }
-/* in-place; inverse != 0 uses exp(+...) ; no scaling either way */
-static void fft_exec(const fft_plan *p, ofdm_c32 *x, int inverse) {
-  int n = p->n;
-  for (int i = 0; i < n; i++) {
-    int r = p->rev[i];
-    if (r > i) {
-      ofdm_c32 t = x[i];
-      x[i] = x[r];
-      x[r] = t;
-    }
+static inline ofdm_c32 cadd(ofdm_c32 a, ofdm_c32 b) { return c32(a.re + b.re, a.im + b.im); }
+static inline ofdm_c32 csub(ofdm_c32 a, ofdm_c32 b) { return c32(a.re - b.re, a.im - b.im); }
+/* forward: a * (-i); inverse: a * (+i) */
+static inline ofdm_c32 mul_mi(ofdm_c32 a, int inv) { return inv ? c32(-a.im, a.re) : c32(a.im, -a.re); }
+static inline ofdm_c32 cmul_f(ofdm_c32 a, ofdm_c32 b) {
+  return c32(fmaf(a.re, b.re, -(a.im * b.im)), fmaf(a.re, b.im, a.im * b.re));
+}
+static void dft8(ofdm_c32 v[8], int inv) {
+  const float h = 0.70710678118654752440f;
+  ofdm_c32 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+  ofdm_c32 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+  ofdm_c32 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+  ofdm_c32 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+  if (inv) {
+    a5 = c32((a5.re - a5.im) * h, (a5.re + a5.im) * h);
+    a7 = c32((-a7.re - a7.im) * h, (a7.re - a7.im) * h);
+  } else {
+    a5 = c32((a5.re + a5.im) * h, (a5.im - a5.re) * h);
+    a7 = c32((a7.im - a7.re) * h, (-a7.re - a7.im) * h);
   }
-  for (int len = 2; len <= n; len <<= 1) {
-    int half = len >> 1, step = n / len;
-    for (int i = 0; i < n; i += len)
-      for (int k = 0; k < half; k++) {
-        ofdm_c32 w = c32(p->wr[k * step], inverse ? -p->wi[k * step] : p->wi[k * step]);
-        ofdm_c32 u = x[i + k];
-        ofdm_c32 v = cmul(x[i + k + half], w);
-        x[i + k] = c32(u.re + v.re, u.im + v.im);
-        x[i + k + half] = c32(u.re - v.re, u.im - v.im);
+  a6 = mul_mi(a6, inv);
+  ofdm_c32 b0 = cadd(a0, a2), b2 = csub(a0, a2);
+  ofdm_c32 b1 = cadd(a1, a3), b3 = mul_mi(csub(a1, a3), inv);
+  ofdm_c32 c0 = cadd(a4, a6), c2 = csub(a4, a6);
+  ofdm_c32 c1 = cadd(a5, a7), c3 = mul_mi(csub(a5, a7), inv);
+  v[0] = cadd(b0, b1);
+  v[4] = csub(b0, b1);
+  v[2] = cadd(b2, b3);
+  v[6] = csub(b2, b3);
+  v[1] = cadd(c0, c1);
+  v[5] = csub(c0, c1);
+  v[3] = cadd(c2, c3);
+  v[7] = csub(c2, c3);
+}
+static void dft4(ofdm_c32 v[4], int inv) {
+  ofdm_c32 s0 = cadd(v[0], v[2]), d0 = csub(v[0], v[2]);
+  ofdm_c32 s1 = cadd(v[1], v[3]), d1 = mul_mi(csub(v[1], v[3]), inv);
+  v[0] = cadd(s0, s1);
+  v[2] = csub(s0, s1);
+  v[1] = cadd(d0, d1);
+  v[3] = csub(d0, d1);
+}
+static void fft_pass(const fft_plan *p, const ofdm_c32 *src, ofdm_c32 *dst, int R, int LS, int inv) {
+  int n = p->n, stride = n / R, tws = n / (LS * R);
+  for (int j = 0; j < stride; j++) {
+    ofdm_c32 v[8];
+    int k = j % LS;
+    for (int q = 0; q < R; q++) v[q] = src[j + q * stride];
+    if (LS > 1)
+      for (int q = 1; q < R; q++) {
+        ofdm_c32 w = p->tw[k * q * tws];
+        if (inv) w.im = -w.im;
+        v[q] = cmul_f(v[q], w);
       }
+    if (R == 8) {
+      dft8(v, inv);
+    } else if (R == 4) {
+      dft4(v, inv);
+    } else {
+      ofdm_c32 sum = cadd(v[0], v[1]), dif = csub(v[0], v[1]);
+      v[0] = sum;
+      v[1] = dif;
+    }
+    int obase = (j - k) * R + k;
+    for (int r = 0; r < R; r++) dst[obase + r * LS] = v[r];
   }
+}
+/* in-place; inverse != 0 uses exp(+...); no scaling either way.  n = 2^k >= 8 */
+static void fft_exec(const fft_plan *p, ofdm_c32 *x, int inverse) {
+  int n = p->n, logn = ilog2_ceil((unsigned)n);
+  ofdm_c32 *a = x, *b = p->buf;
+  int LS = 1;
+  int lead = (logn % 3 == 1) ? 2 : (logn % 3 == 2) ? 4 : 0;
+  if (lead) {
+    fft_pass(p, a, b, lead, LS, inverse);
+    LS *= lead;
+    ofdm_c32 *t = a; a = b; b = t;
+  }
+  while (LS < n) {
+    fft_pass(p, a, b, 8, LS, inverse);
+    LS *= 8;
+    ofdm_c32 *t = a; a = b; b = t;
+  }
+  if (a != x) memcpy(x, a, sizeof(ofdm_c32) * (size_t)n);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Deterministic elementary functions.  libm (CPU) and ocml (GPU) differ in the
+ * last bit, which is enough to make two float32 receivers disagree on a slicer
+ * boundary.  The engine evaluates the same plain IEEE operations (fma() where
+ * written, every other operation separately rounded), so these have the same
+ * bits on both sides.  Accuracy is that of a good libm (tests check <= 2 ulp). */
+/* ------------------------------------------------------------------------ */
+/* sin and cos of a float32 argument (|x| < ~1e6): reduction by multiples of pi/2 in
+ * float64 (two-part pi/2), Cephes sinf/cosf polynomials on [-pi/4, pi/4].      */
+void orc_sincosf(float x, float *sn, float *cs) {
+  double xd = (double)x;
+  double kd = rint(xd * 0.63661977236758134308);
+  double yd = fma(-kd, 1.57079632673412561417e+00, xd);
+  yd = fma(-kd, 6.07710050650619224932e-11, yd);
+  float y = (float)yd;
+  int q = (int)kd & 3;
+  float z = y * y;
+  float ps = -1.9515295891e-4f;
+  ps = ps * z + 8.3321608736e-3f;
+  ps = ps * z - 1.6666654611e-1f;
+  ps = ps * z;
+  ps = ps * y + y;
+  float pc = 2.443315711809948e-5f;
+  pc = pc * z - 1.388731625493765e-3f;
+  pc = pc * z + 4.166664568298827e-2f;
+  pc = pc * z;
+  pc = pc * z - 0.5f * z;
+  pc = pc + 1.0f;
+  float s_, c_;
+  if (q & 1) {
+    s_ = pc;
+    c_ = -ps;
+  } else {
+    s_ = ps;
+    c_ = pc;
+  }
+  if (q & 2) {
+    s_ = -s_;
+    c_ = -c_;
+  }
+  *sn = s_;
+  *cs = c_;
+}
+/* exp(j ph) in float64 for the NCO: ph is first wrapped to [-pi, pi] exactly as
+ * written, then reduced by pi/2 and evaluated with the fdlibm kernel polynomials. */
+typedef struct {
+  double re, im;
+} dcx;
+dcx orc_expj(double ph) {
+  ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
+  double kd = rint(ph * 0.63661977236758134308);
+  double y = fma(-kd, 1.57079632673412561417e+00, ph);
+  y = fma(-kd, 6.07710050650619224932e-11, y);
+  int q = (int)kd & 3;
+  double z = y * y;
+  double r = 1.58969099521155010221e-10;
+  r = fma(z, r, -2.50507602534068634195e-08);
+  r = fma(z, r, 2.75573137070700676789e-06);
+  r = fma(z, r, -1.98412698298579493134e-04);
+  r = fma(z, r, 8.33333333332248946124e-03);
+  r = fma(z, r, -1.66666666666666324348e-01);
+  double sn = fma(y * z, r, y);
+  double c = -1.13596475577881948265e-11;
+  c = fma(z, c, 2.08757232129817482790e-09);
+  c = fma(z, c, -2.75573143513906633035e-07);
+  c = fma(z, c, 2.48015872894767294178e-05);
+  c = fma(z, c, -1.38888888888741095749e-03);
+  c = fma(z, c, 4.16666666666666019037e-02);
+  double cs = fma(z * z, c, fma(-0.5, z, 1.0));
+  dcx o;
+  if (q & 1) {
+    o.im = cs;
+    o.re = -sn;
+  } else {
+    o.im = sn;
+    o.re = cs;
+  }
+  if (q & 2) {
+    o.im = -o.im;
+    o.re = -o.re;
+  }
+  return o;
+}
+static inline dcx dmul(dcx a, dcx b) {
+  dcx r;
+  r.re = a.re * b.re - a.im * b.im;
+  r.im = a.re * b.im + a.im * b.re;
+  return r;
+}
+
+/* array forms for the test-suite (tests/test_oracle.py checks them against libm / numpy.fft) */
+void orc_sincosf_vec(const float *x, uint64_t n, float *sn, float *cs) {
+  for (uint64_t i = 0; i < n; i++) orc_sincosf(x[i], &sn[i], &cs[i]);
+}
+void orc_expj_vec(const double *ph, uint64_t n, double *re, double *im) {
+  for (uint64_t i = 0; i < n; i++) {
+    dcx z = orc_expj(ph[i]);
+    re[i] = z.re;
+    im[i] = z.im;
+  }
+}
+int orc_fft(ofdm_c32 *x, int n, int inverse) {
+  if (n < 8 || (n & (n - 1))) return OFDM_E_INVAL;
+  fft_plan p;
+  fft_plan_init(&p, n);
+  fft_exec(&p, x, inverse);
+  fft_plan_free(&p);
+  return OFDM_OK;
+}
+
+/* Sum of per-lane partial sums the way the engine's workgroup of T = N/8 threads adds them: groups of 64
+ * lanes by a butterfly (distance 32, 16, .. 1; float addition is commutative, so every lane ends with the
+ * same value), the groups then in order; fewer than 64 lanes: in order.  Normative for the two float32
+ * reductions of the receiver (coarse-offset correlation, PLL error) -- a pairwise tree, at least as accurate
+ * as GNU Radio's sequential loop.                                                                      */
+static float lane_tree_sum(const float *part, int T) {
+  if (T < 64) {
+    float s = 0.0f;
+    for (int i = 0; i < T; i++) s = s + part[i];
+    return s;
+  }
+  float s = 0.0f;
+  for (int w = 0; w < T / 64; w++) {
+    float v[64], u[64];
+    for (int l = 0; l < 64; l++) v[l] = part[w * 64 + l];
+    for (int d = 32; d > 0; d >>= 1) {
+      for (int l = 0; l < 64; l++) u[l] = v[l] + v[l ^ d];
+      for (int l = 0; l < 64; l++) v[l] = u[l];
+    }
+    if (T == 64) return v[0];
+    s = s + v[0];
+  }
+  return s;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -550,32 +749,59 @@ static inline int64_t q40(float v) {
   return (int64_t)llrint((double)v * QSCALE);
 }
 
-/* gr_fft_filter_ccc(1, taps) == causal linear convolution with zero pre-history
- * (ofdm_receiver.py~:76,131).  One fmaf chain per output sample, tap order 0..nt-1. */
+/* gr_fft_filter_ccc(1, taps) (ofdm_receiver.py~:76,131), the way GNU Radio runs it [SURVEY A.5]: overlap-save
+ * with transform length F = 2 * 2^ceil(log2(ntaps)) (at least 64 here) and B = F - ntaps + 1 outputs per block on
+ * the grid b*B of the stream.  Block b transforms the F samples x[b*B - (ntaps-1) .. b*B + B) (zero before the
+ * stream starts), multiplies bin by bin with the transformed taps -- taps zero-padded to F, transformed, scaled by
+ * 1/F; computed in float64 and rounded once, where GR rounds FFTW's float32 result -- as volk does (two products
+ * and one add per part), transforms back (unnormalised) and keeps the last B points.  Result == causal linear
+ * convolution with zero pre-history, to float32 rounding.  A final partial block is processed with zeros after
+ * the end of the input (GR would wait for more samples).  The transform is fft_exec above.                     */
+int orc_filter_fft_len(int ntaps) {
+  int p2 = 1;
+  while (p2 < ntaps) p2 <<= 1;
+  int f = 2 * p2;
+  return f < 64 ? 64 : f;
+}
 static void chan_filter(const ofdm_cfg *cfg, const ofdm_c32 *x, uint64_t n, ofdm_c32 *y) {
   int nt = (int)cfg->ntaps;
-  enum { BLK = 1024 };
-  float are[BLK], aim[BLK];
-  for (uint64_t b = 0; b < n; b += BLK) {
-    int m = (int)((n - b < BLK) ? (n - b) : BLK);
-    for (int i = 0; i < m; i++) are[i] = aim[i] = 0.0f;
-    for (int k = 0; k < nt; k++) {
-      float h = cfg->taps[k];
-      /* outputs b+i with b+i-k >= 0 */
-      int i0 = 0;
-      if ((uint64_t)k > b) i0 = (int)((uint64_t)k - b);
-      if (i0 >= m) {
-        /* x index negative for the whole block: contributes fmaf(h, 0, acc) = acc */
-        continue;
-      }
-      const ofdm_c32 *xs = x + ((int64_t)b - (int64_t)k); /* valid from i0 */
-      for (int i = i0; i < m; i++) {
-        are[i] = fmaf(h, xs[i].re, are[i]);
-        aim[i] = fmaf(h, xs[i].im, aim[i]);
-      }
+  int F = orc_filter_fft_len(nt), B = F - nt + 1, ntm1 = nt - 1;
+  fft_plan plan;
+  fft_plan_init(&plan, F);
+  ofdm_c32 *H = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)F);
+  ofdm_c32 *w = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * (size_t)F);
+  {
+    double *cs = (double *)malloc(sizeof(double) * (size_t)F), *sn = (double *)malloc(sizeof(double) * (size_t)F);
+    for (int m = 0; m < F; m++) {
+      double a = -2.0 * M_PI * (double)m / (double)F;
+      cs[m] = cos(a);
+      sn[m] = sin(a);
     }
-    for (int i = 0; i < m; i++) y[b + i] = c32(are[i], aim[i]);
+    for (int k = 0; k < F; k++) {
+      double re = 0.0, im = 0.0;
+      for (int i = 0; i < nt; i++) {
+        int idx = (int)(((long long)k * i) % F);
+        re = re + (double)cfg->taps[i] * cs[idx];
+        im = im + (double)cfg->taps[i] * sn[idx];
+      }
+      H[k] = c32((float)(re / (double)F), (float)(im / (double)F));
+    }
+    free(cs);
+    free(sn);
   }
+  for (uint64_t b0 = 0; b0 < n; b0 += (uint64_t)B) {
+    for (int i = 0; i < F; i++) {
+      int64_t xi = (int64_t)b0 - ntm1 + i;
+      w[i] = (xi >= 0 && (uint64_t)xi < n) ? x[xi] : c32(0.0f, 0.0f);
+    }
+    fft_exec(&plan, w, 0);
+    for (int k = 0; k < F; k++) w[k] = cmul(w[k], H[k]);
+    fft_exec(&plan, w, 1);
+    for (int o = 0; o < B && b0 + (uint64_t)o < n; o++) y[b0 + (uint64_t)o] = w[ntm1 + o];
+  }
+  free(w);
+  free(H);
+  fft_plan_free(&plan);
 }
 
 /* ofdm_sync_pn(N, CP) (ofdm_receiver.py~:97-101): delay N/2, conj, multiply, two
@@ -668,6 +894,7 @@ static void peak_detect(const ofdm_cfg *cfg, const float *u, uint64_t n, vec *pe
 typedef struct {
   ofdm_c32 pos[OFDM_MAX_ARITY];
   int arity, nbits, occ, nmap;
+  int lanes; /* N/8: threads of the engine's frame workgroup (order of the float32 reductions) */
   int map[OFDM_MAX_FFT];
   ofdm_c32 dfe[OFDM_MAX_FFT];
   float phase, freq, phase_gain, freq_gain, eq_gain;
@@ -711,8 +938,13 @@ static unsigned sink_slicer(const frame_sink *s, ofdm_c32 x) {
 /* digital_ofdm_frame_sink::demapper */
 static unsigned sink_demapper(frame_sink *s, const ofdm_c32 *in, uint8_t *out, ofdm_c32 *derot) {
   unsigned i = 0, bytes_produced = 0;
-  ofdm_c32 carrier = c32(cosf(s->phase), sinf(s->phase));
-  ofdm_c32 acc = c32(0.0f, 0.0f);
+  ofdm_c32 carrier;
+  orc_sincosf(s->phase, &carrier.im, &carrier.re); /* gr_expj(d_phase) */
+  /* acc += sigrot * conj(closest): lane t = i mod T of the engine's workgroup sums its carriers in order, the
+   * lanes are then added as lane_tree_sum does (normative order of this float32 reduction) */
+  int T = s->lanes;
+  float pre[OFDM_MAX_FFT / 8], pim[OFDM_MAX_FFT / 8];
+  for (int t = 0; t < T; t++) pre[t] = pim[t] = 0.0f;
   unsigned nmap = (unsigned)s->nmap, nb = (unsigned)s->nbits;
   if (derot) memset(derot, 0, sizeof(ofdm_c32) * (size_t)s->occ);
   while (i < nmap) {
@@ -728,8 +960,8 @@ static unsigned sink_demapper(frame_sink *s, const ofdm_c32 *in, uint8_t *out, o
       unsigned bits = sink_slicer(s, sigrot);
       ofdm_c32 closest = s->pos[bits];
       ofdm_c32 e = cmul_conj(sigrot, closest);
-      acc.re = acc.re + e.re;
-      acc.im = acc.im + e.im;
+      pre[i % (unsigned)T] = pre[i % (unsigned)T] + e.re;
+      pim[i % (unsigned)T] = pim[i % (unsigned)T] + e.im;
       if (cnorm(sigrot) > 0.001f) {
         ofdm_c32 q = cdiv(closest, sigrot);
         s->dfe[i].re = s->dfe[i].re + s->eq_gain * (q.re - s->dfe[i].re);
@@ -753,7 +985,7 @@ static unsigned sink_demapper(frame_sink *s, const ofdm_c32 *in, uint8_t *out, o
       s->partial_byte = 0;
     }
   }
-  float angle = atan2f(acc.im, acc.re);
+  float angle = orc_atan2f(lane_tree_sum(pim, T), lane_tree_sum(pre, T)); /* arg(acc), bit-reproducible form */
   s->freq = s->freq - s->freq_gain * angle;
   s->phase = s->phase + s->freq - s->phase_gain * angle;
   if (s->phase >= 6.28318530717958647692f) s->phase -= 6.28318530717958647692f;
@@ -828,11 +1060,18 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   float *ang = (float *)vec_push(&r->angles, npk);
   double *Phi = (double *)malloc(sizeof(double) * (npk + 1));
   double *step = (double *)malloc(sizeof(double) * (npk + 1));
-  Phi[0] = 0.0;
+  /* The phase a flag starts from is kept modulo one turn as an integer (unit 2^-64 turn): integer addition is
+   * associative, so the engine's parallel scan over the flags gives the same bits as this running sum. */
+  uint64_t phi_u = 0;
   for (uint64_t j = 0; j < npk; j++) {
     ang[j] = orc_atan2f(P[pk[j]].im, P[pk[j]].re);
     step[j] = (double)(sens * ang[j]);
-    if (j + 1 < npk) Phi[j + 1] = Phi[j] + step[j] * (double)(pk[j + 1] - pk[j]);
+    Phi[j] = (double)(int64_t)phi_u * 3.4061215800865545e-19; /* 2 pi / 2^64: phase in [-pi, pi) */
+    if (j + 1 < npk) {
+      double t = step[j] * (double)(pk[j + 1] - pk[j]) * 0.15915494309189533577; /* turns */
+      t -= floor(t);
+      phi_u += (uint64_t)(t * 18446744073709551616.0);
+    }
   }
   free(P);
 
@@ -860,6 +1099,7 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   sk->arity = (int)cfg->arity;
   sk->nbits = orc_nbits(cfg);
   sk->occ = occ;
+  sk->lanes = N / 8;
   memcpy(sk->pos, cfg->constellation, sizeof(ofdm_c32) * cfg->arity);
   sk->nmap = orc_carrier_map(occ, occ, cfg->carrier_map, sk->map, OFDM_MAX_FFT);
   sk->phase_gain = cfg->phase_gain;
@@ -876,6 +1116,10 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   uint64_t base = 0;
   uint64_t next_pk = 0;     /* first peak with index >= scan start */
   uint64_t cur_frame_data = 0;
+  /* NCO recurrence state of the current frame */
+  dcx *nco_base = (dcx *)malloc(sizeof(dcx) * (size_t)(N / 8));
+  dcx nco_RL = {1.0, 0.0}, nco_RT = {1.0, 0.0};
+  uint64_t nco_j = 0;
   while (base + (uint64_t)L + (uint64_t)N < n) { /* the scan touches trigger[base+L+N] */
     /* search trigger[base+N .. base+L+N] unless already in PREAMBLE */
     uint64_t lo = base + (uint64_t)N, hi = base + (uint64_t)L + (uint64_t)N;
@@ -909,29 +1153,67 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
     }
     r->st.symbols++;
 
-    /* --- sigmix: chan_filt * nco over this symbol's N samples --------------- */
+    /* --- sigmix: chan_filt * nco over this symbol's N samples ---------------
+     * The NCO phasor exp(j phi[n]) is evaluated by recurrence in float64 (GR's own NCO is a recurrence too), in the
+     * normative order the engine uses: the symbol's sample i = t + m*T (T = N/8, t < T, m < 8) gets
+     *   data symbol k >= 1 of the frame of flag j:  base_t(k) * RT^m,  base_t(k) = base_t(k-1) * RL,
+     *       base_t(0) = expj(Phi[j] + step[j]*(2 - N + t)),  RL = expj(step[j]*L),  RT = expj(step[j]*T),
+     *   the preamble symbol (it ENDS on the flag, so it runs on the previous flag's line except for its
+     *       last sample):  Ap_t * RTp^m,  Ap_t = expj(Phi[j-1] + step[j-1]*(n - pk[j-1] + 1)) at n = first
+     *       sample + t, RTp = expj(step[j-1]*T); sample N-1 = expj(Phi[j] + step[j]),
+     *   products taken left to right, rounded to float32 at the end; if the previous flag lies inside the preamble
+     *   symbol every sample evaluates its own closed form.                                                   */
     {
-      /* cnt = number of flags at or before the sample (binary search at the symbol start) */
-      uint64_t lo2 = 0, hi2 = npk;
-      while (lo2 < hi2) {
-        uint64_t mid = (lo2 + hi2) / 2;
-        if (pk[mid] <= sym_start)
-          lo2 = mid + 1;
-        else
-          hi2 = mid;
-      }
-      uint64_t cnt = lo2;
-      for (int m = 0; m < N; m++) {
-        uint64_t idx = sym_start + (uint64_t)m;
-        while (cnt < npk && pk[cnt] <= idx) cnt++;
-        double ph = 0.0;
-        if (cnt > 0) {
-          uint64_t j = cnt - 1;
-          ph = Phi[j] + step[j] * (double)(idx - pk[j] + 1);
+      int T = N / 8;
+      if (flag) {
+        uint64_t j = next_pk - 1; /* the flag that started this frame */
+        double st = step[j];
+        nco_j = j;
+        nco_RL = orc_expj(st * (double)L);
+        nco_RT = orc_expj(st * (double)T);
+        for (int t = 0; t < T; t++) nco_base[t] = orc_expj(Phi[j] + st * (double)(2 - N + t));
+        int pre_simple = (j == 0) || (pk[j - 1] <= sym_start);
+        if (pre_simple) {
+          dcx RTp = {1.0, 0.0};
+          double stq = 0.0;
+          if (j > 0) {
+            stq = step[j - 1];
+            RTp = orc_expj(stq * (double)T);
+          }
+          dcx Rflag = orc_expj(Phi[j] + st);
+          for (int t = 0; t < T; t++) {
+            dcx rr = {1.0, 0.0};
+            if (j > 0) rr = orc_expj(Phi[j - 1] + stq * (double)((int64_t)(sym_start + (uint64_t)t) - (int64_t)pk[j - 1] + 1));
+            for (int m = 0; m < 8; m++) {
+              int i = t + m * T;
+              ofdm_c32 rot = c32((float)rr.re, (float)rr.im);
+              if (i == N - 1) rot = c32((float)Rflag.re, (float)Rflag.im);
+              win[i] = cmul(y[sym_start + (uint64_t)i], rot);
+              rr = dmul(rr, RTp);
+            }
+          }
+        } else {
+          for (int i = 0; i < N; i++) {
+            uint64_t idx = sym_start + (uint64_t)i;
+            int64_t q = (int64_t)j;
+            while (q >= 0 && pk[q] > idx) q--;
+            double ph = 0.0;
+            if (q >= 0) ph = Phi[q] + step[q] * (double)(idx - pk[q] + 1);
+            dcx rr = orc_expj(ph);
+            win[i] = cmul(y[idx], c32((float)rr.re, (float)rr.im));
+          }
         }
-        ph = ph - 2.0 * M_PI * floor(ph / (2.0 * M_PI) + 0.5);
-        ofdm_c32 rot = c32((float)cos(ph), (float)sin(ph));
-        win[m] = cmul(y[idx], rot);
+      } else {
+        (void)nco_j;
+        for (int t = 0; t < T; t++) {
+          nco_base[t] = dmul(nco_base[t], nco_RL);
+          dcx rr = nco_base[t];
+          for (int m = 0; m < 8; m++) {
+            int i = t + m * T;
+            win[i] = cmul(y[sym_start + (uint64_t)i], c32((float)rr.re, (float)rr.im));
+            rr = dmul(rr, nco_RT);
+          }
+        }
       }
     }
 
@@ -949,12 +1231,16 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
       int index = 0;
       float mx = 0.0f;
       for (int i = zl - shift; i < zl + shift; i++) {
-        float sum = 0.0f;
+        /* sum_j kd[j] * sd[i+j]: lane t = j mod T sums its terms in order, lanes added by lane_tree_sum */
+        int T = N / 8;
+        float part[OFDM_MAX_FFT / 8];
+        for (int t = 0; t < T; t++) part[t] = 0.0f;
         for (int j = 0; j < occ; j++) {
           int q = i + j;
           float s2 = (q >= 0 && q < N) ? sd[q] : 0.0f;
-          sum = sum + kd[j] * s2;
+          part[j % T] = part[j % T] + kd[j] * s2;
         }
+        float sum = lane_tree_sum(part, T);
         if (sum > mx) {
           mx = sum;
           index = i;
@@ -965,7 +1251,8 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
       {
         double a = -2.0 * M_PI * (double)coarse * (double)CP / (double)N * 1.0;
         float af = (float)a;
-        ofdm_c32 comp = c32(cosf(af), sinf(af));
+        ofdm_c32 comp;
+        orc_sincosf(af, &comp.im, &comp.re); /* gr_expj(af) */
         hinv[0] = cdiv(cfg->known_symbol[0], cmul(comp, YAT(zl + coarse)));
         for (int i = 2; i < occ; i += 2) {
           hinv[i] = cdiv(cfg->known_symbol[i], cmul(comp, YAT(i + zl + coarse)));
@@ -977,7 +1264,8 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
     {
       double a = -2.0 * M_PI * (double)coarse * (double)CP / (double)N * (double)phase_count;
       float af = (float)a;
-      ofdm_c32 comp = c32(cosf(af), sinf(af));
+      ofdm_c32 comp;
+      orc_sincosf(af, &comp.im, &comp.re);
       for (int i = 0; i < occ; i++) acq[i] = cmul(cmul(hinv[i], comp), YAT(i + zl + coarse));
       phase_count++;
       if (phase_count == 1000) phase_count = 1; /* MAX_NUM_SYMBOLS */
@@ -1030,6 +1318,7 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   *(uint64_t *)vec_push(&r->raw_off, 1) = r->raw.n;
   *(uint64_t *)vec_push(&r->pay_off, 1) = r->payload.n;
 
+  free(nco_base);
   free(sk);
   free(derot);
   free(sd);

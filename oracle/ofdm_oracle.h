@@ -16,6 +16,11 @@ typedef struct orc_rx_result orc_rx_result;
 
 int orc_nbits(const ofdm_cfg *cfg);
 float orc_atan2f(float y, float x);
+void orc_sincosf(float x, float *sn, float *cs);
+void orc_sincosf_vec(const float *x, uint64_t n, float *sn, float *cs);
+void orc_expj_vec(const double *ph, uint64_t n, double *re, double *im);
+int orc_fft(ofdm_c32 *x, int n, int inverse);
+int orc_filter_fft_len(int ntaps);
 uint32_t orc_crc32(const uint8_t *buf, uint64_t len);
 int orc_framed_len(const ofdm_cfg *cfg, uint32_t payload_len, uint32_t *out);
 int orc_make_packet(const ofdm_cfg *cfg, const uint8_t *payload, uint32_t len, uint8_t *out, uint32_t *outlen);

@@ -32,6 +32,12 @@ def lib():
         L.orc_crc32.argtypes = [vp, C.c_uint64]
         L.orc_atan2f.restype = C.c_float
         L.orc_atan2f.argtypes = [C.c_float, C.c_float]
+        L.orc_sincosf_vec.restype = None
+        L.orc_sincosf_vec.argtypes = [vp, C.c_uint64, vp, vp]
+        L.orc_expj_vec.restype = None
+        L.orc_expj_vec.argtypes = [vp, C.c_uint64, vp, vp]
+        L.orc_fft.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_filter_fft_len.argtypes = [C.c_int]
         L.orc_framed_len.argtypes = [C.POINTER(_abi.ofdm_cfg), C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_make_packet.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
         L.orc_unmake_packet.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, C.c_uint32, vp, C.POINTER(C.c_uint32),
@@ -68,6 +74,33 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def sincosf(x):
+    x = np.ascontiguousarray(x, np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().orc_sincosf_vec(_ptr(x), x.size, _ptr(s), _ptr(c))
+    return s, c
+
+
+def expj(ph):
+    ph = np.ascontiguousarray(ph, np.float64)
+    re, im = np.empty_like(ph), np.empty_like(ph)
+    lib().orc_expj_vec(_ptr(ph), ph.size, _ptr(re), _ptr(im))
+    return re + 1j * im
+
+
+def fft(x, inverse=False):
+    """The normative transform (unnormalised either way), in place on a copy."""
+    y = np.ascontiguousarray(x, np.complex64).copy()
+    rc = lib().orc_fft(_ptr(y), y.size, 1 if inverse else 0)
+    if rc:
+        raise ValueError("orc_fft: %d" % rc)
+    return y
+
+
+def filter_fft_len(ntaps):
+    return int(lib().orc_filter_fft_len(int(ntaps)))
 
 
 def crc32(data):
