@@ -106,9 +106,44 @@ __device__ __forceinline__ c32 tw_get(const c32* __restrict__ tw, int idx) {
 //           otherwise written to `dst` (padded LDS).
 // INPLACE: dst == src; `sync` is called between the last read and the first write (radix 8 only:
 //           one butterfly per thread, so all of a thread's reads precede all of its writes).
-template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG, bool INPLACE = false, typename SyncFn = int>
-__device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* dst, const c32* __restrict__ tw,
-                                         SyncFn sync = 0) {
+// Twiddle sources.  FftTwTable reads the forward table (the usual case); FftTwRegs holds the thread's own
+// twiddles of every radix-8 pass in registers (a thread's butterfly index is its thread index there, so they never
+// change): for kernels that run transform after transform and cannot afford the load latency in each.
+struct FftTwTable {
+  const c32* __restrict__ tw;
+  template <int N, int LS, int R, bool INV>
+  __device__ __forceinline__ c32 get(int k, int q) const {
+    return tw_get<INV>(tw, k * q * (N / (LS * R)));
+  }
+};
+template <int N>
+struct FftTwRegs {
+  static constexpr int LOG = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : (N == 512) ? 9 : 10;
+  static constexpr int LS0 = (LOG % 3 == 1) ? 2 : (LOG % 3 == 2) ? 4 : 8;  // sub-length of the first twiddled pass
+  static constexpr int NP = (N == 64) ? 1 : (N == 1024) ? 3 : 2;            // twiddled (radix-8) passes
+  c32 w[NP][7];
+  __device__ __forceinline__ void load(const c32* __restrict__ tw, int t) {
+    int ls = LS0;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+#pragma unroll
+      for (int q = 1; q < 8; q++) w[p][q - 1] = tw[(t % ls) * q * (N / (ls * 8))];
+      ls *= 8;
+    }
+  }
+  template <int NN, int LS, int R, bool INV>
+  __device__ __forceinline__ c32 get(int, int q) const {
+    static_assert(NN == N && R == 8, "register twiddles exist for the radix-8 passes");
+    constexpr int p = (LS == LS0) ? 0 : (LS == LS0 * 8) ? 1 : 2;
+    c32 v = w[p][q - 1];
+    if (INV) v.im = -v.im;
+    return v;
+  }
+};
+
+template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG, bool INPLACE = false, typename SyncFn = int,
+          typename TwFn = FftTwTable>
+__device__ __forceinline__ void fft_pass_tw(c32 e[8], int t, const c32* src, c32* dst, const TwFn& twf, SyncFn sync = 0) {
   constexpr int T = N / 8;        // threads per transform
   constexpr int NB = 8 / R;       // butterflies per thread
   static_assert(!INPLACE || (NB == 1 && !FROM_REG && !TO_REG), "in-place passes are radix-8 middle passes");
@@ -126,10 +161,9 @@ __device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* d
         v[q] = src[lpad(j + q * STRIDE)];
     }
     const int k = (LS == 1) ? 0 : (j % LS);
-    if (LS > 1) {
-      constexpr int TWS = N / (LS * R);
+    if constexpr (LS > 1) {
 #pragma unroll
-      for (int q = 1; q < R; q++) v[q] = cmul_f(v[q], tw_get<INV>(tw, k * q * TWS));
+      for (int q = 1; q < R; q++) v[q] = cmul_f(v[q], twf.template get<N, LS, R, INV>(k, q));
     }
     if (R == 8) {
       dft8<INV>(v);
@@ -148,6 +182,12 @@ __device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* d
         dst[lpad(obase + r * LS)] = v[r];
     }
   }
+}
+
+template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG, bool INPLACE = false, typename SyncFn = int>
+__device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* dst, const c32* __restrict__ tw,
+                                         SyncFn sync = 0) {
+  fft_pass_tw<N, R, LS, INV, FROM_REG, TO_REG, INPLACE, SyncFn, FftTwTable>(e, t, src, dst, FftTwTable{tw}, sync);
 }
 
 // Full transform.  e[m] holds x[t + m*N/8] on entry and X[t + m*N/8] on exit.
@@ -213,40 +253,40 @@ __device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __
 // The same transform (same butterflies, same twiddles, same results bit for bit) in ONE LDS buffer of
 // fft_lds_points(N) points for every N: middle passes run in place.  sync() is also called on entry, so that
 // back-to-back transforms in the same scratch are safe when the N/8 threads span more than one wave.
-template <int N, bool INV, typename SyncFn>
-__device__ __forceinline__ void fft_run1(c32 e[8], int t, c32* A, const c32* __restrict__ tw, SyncFn sync) {
+template <int N, bool INV, typename SyncFn, typename TwFn>
+__device__ __forceinline__ void fft_run1(c32 e[8], int t, c32* A, const TwFn& tw, SyncFn sync) {
   sync();
   if constexpr (N == 64) {
-    fft_pass<64, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass_tw<64, 8, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<64, 8, 8, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass_tw<64, 8, 8, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 128) {
-    fft_pass<128, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass_tw<128, 2, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<128, 8, 2, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass_tw<128, 8, 2, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<128, 8, 16, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass_tw<128, 8, 16, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 256) {
-    fft_pass<256, 4, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass_tw<256, 4, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<256, 8, 4, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass_tw<256, 8, 4, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<256, 8, 32, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass_tw<256, 8, 32, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 512) {
-    fft_pass<512, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass_tw<512, 8, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<512, 8, 8, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass_tw<512, 8, 8, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<512, 8, 64, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass_tw<512, 8, 64, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 1024) {
-    fft_pass<1024, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass_tw<1024, 2, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<1024, 8, 2, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass_tw<1024, 8, 2, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<1024, 8, 16, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass_tw<1024, 8, 16, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<1024, 8, 128, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass_tw<1024, 8, 128, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
   } else {
-    fft_run<N, INV>(e, t, A, tw, sync);  // N >= 2048 already works in one buffer
+    static_assert(N <= 1024, "fft_run1 is built for the channel filter's lengths; fft_run handles N >= 2048 in one buffer");
   }
 }

@@ -370,8 +370,14 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
     st_acc[i] += now_ - st_last;                                             \
     st_last = now_;                                                          \
   } while (0)
+#define STAMP_VM(i)                                                          \
+  do {                                                                       \
+    __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */            \
+    STAMP(i);                                                                \
+  } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP_VM(i) do { } while (0)
 #endif
 
 // Phase ablation for timing experiments exists only in the diagnostic build (make diag ->
@@ -393,7 +399,7 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 template <int F, int W>
 __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
-  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
   extern __shared__ __align__(16) unsigned char smem[];
@@ -446,6 +452,23 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   // filter front: first sample of the next block to transform; the ring slot of the tile's first sample
   uint64_t fbs = (ws / (uint64_t)B) * (uint64_t)B;
   int rbase = 0;
+  // per-thread constants of the filter transforms (a thread keeps its place t in its block for the whole kernel):
+  // its twiddles of both radix-8 passes, its 8 bins of the transformed taps; and the input window of the NEXT
+  // round, loaded a round ahead so that its HBM latency hides behind the transforms and the metric phase
+  const int gF = tid / TF, tF = tid % TF;
+  FftTwRegs<F> twr;
+  twr.load(p.twF, tF);
+  c32 Hr[8], xn[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) Hr[m] = p.Hf[tF + m * TF];
+  {
+    const int64_t x0 = (int64_t)fbs + (int64_t)gF * B - ntm1 + tF;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int64_t xi = x0 + m * TF;
+      xn[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
+    }
+  }
   __syncthreads();
 
   for (uint64_t tile = tile_first; tile < tile_own1; tile++, rbase = (rbase + T >= R) ? rbase + T - R : rbase + T) {
@@ -466,33 +489,41 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       const int g = tl / TF, t = tl % TF;
       c32* sc = fsc + g * fft_lds_points(F);
       const int64_t bs = (int64_t)fbs + (int64_t)g * B;  // first output sample of this thread's block
-      const int64_t x0 = bs - ntm1 + t;
       c32 e[8];
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        const int64_t xi = x0 + m * TF;
-        e[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
+      for (int m = 0; m < 8; m++) e[m] = xn[m];
+      STAMP_VM(0);
+      fbs += (uint64_t)BPR * (uint64_t)B;
+      {
+        const int64_t x0 = (int64_t)fbs + (int64_t)g * B - ntm1 + t;
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          const int64_t xi = x0 + m * TF;
+          xn[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
+        }
       }
       if (!SYNC_ABLATE(p, 1)) {
         if constexpr (TF <= WAVE) {
-          fft_run1<F, false>(e, t, sc, p.twF, FftWaveSync());
+          fft_run1<F, false>(e, t, sc, twr, FftWaveSync());
         } else {
-          fft_run1<F, false>(e, t, sc, p.twF, FftBlockSync());
+          fft_run1<F, false>(e, t, sc, twr, FftBlockSync());
         }
+        STAMP(11);
 #pragma unroll
-        for (int m = 0; m < 8; m++) e[m] = cmul(e[m], p.Hf[t + m * TF]);  // volk_32fc_x2_multiply_32fc
+        for (int m = 0; m < 8; m++) e[m] = cmul(e[m], Hr[m]);  // volk_32fc_x2_multiply_32fc
+        STAMP(12);
         if constexpr (TF <= WAVE) {
-          fft_run1<F, true>(e, t, sc, p.twF, FftWaveSync());
+          fft_run1<F, true>(e, t, sc, twr, FftWaveSync());
         } else {
-          fft_run1<F, true>(e, t, sc, p.twF, FftBlockSync());
+          fft_run1<F, true>(e, t, sc, twr, FftBlockSync());
         }
       }
+      STAMP(13);
       const int rel0 = rbase + (int)(bs - t0s) - ntm1 + t;  // ring-relative position of transform point t
 #pragma unroll
       for (int m = 0; m < 8; m++) {
         if (t + m * TF >= ntm1) ys[sync_lp(ring_wrap(rel0 + m * TF, R))] = e[m];
       }
-      fbs += (uint64_t)BPR * (uint64_t)B;
     }
     STAMP(1);
     __syncthreads();  // B2: the tile's y is in the ring
@@ -838,7 +869,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   }
 #ifdef SYNC_STAMPS
   if (p.stamps && threadIdx.x == 0)
-    for (int i = 0; i < 12; i++) p.stamps[blockIdx.x * 12 + i] = st_acc[i];
+    for (int i = 0; i < 16; i++) p.stamps[blockIdx.x * 16 + i] = st_acc[i];
 #endif
 }
 
