@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OFDM_ABI_VERSION 3
+#define OFDM_ABI_VERSION 4
 
 #define OFDM_MAX_FFT 4096
 #define OFDM_MAX_CARRIER_HEX 1024 /* hex digits of a carrier map: OFDM_MAX_FFT / 4 */
@@ -263,7 +263,12 @@ int ofdm_sense_redecide(ofdm_handle *h, const ofdm_sense_cfg *sc);
  *    steps and swallowed marks -- they replace whatever that call detects up to trust_after, in the start of its
  *    overlap where its own detector has not settled -- and the NCO line (phase, step at
  *    pred_flag, which may be negative) of the flag before them, in force up to the call's
- *    first flag.  enable = 0 returns to independent calls. */
+ *    first flag.  enable = 0 returns to independent calls.
+ *  - ofdm_rx_set_origin: index, in the whole capture, of the first sample the following ofdm_rx calls are
+ *    given (default 0).  gr_fft_filter_ccc (ofdm_receiver.py~:76) works in blocks that start at multiples of its
+ *    block length counted from the first sample the flow graph ever saw; the engine lays its filter blocks on
+ *    that same grid, so a capture handed over in pieces is filtered exactly as one call would filter it. */
+int ofdm_rx_set_origin(ofdm_handle *h, uint64_t first_sample_index);
 int ofdm_rx_packet_pos(ofdm_handle *h, uint64_t *pos, int cap, int *n);
 int ofdm_rx_nco_state(ofdm_handle *h, uint64_t *flags, uint64_t *phase, double *step, uint8_t *swallowed,
                       int cap, int *n);

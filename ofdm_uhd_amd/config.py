@@ -74,33 +74,48 @@ def channel_filter_taps(fft_length, occupied_tones):
     return firdes.low_pass(1.0, 1.0, bw + tb, tb, firdes.WIN_HAMMING)
 
 
-def carrier_map(occupied_tones, container, carriers="FE7F"):
-    """Subcarrier map of digital_ofdm_mapper_bcv (container = fft_length, ofdm.py:106)
-    and digital_ofdm_frame_sink (container = occupied_tones, ofdm.py:240): the hex
-    string is grown with 'f' on both sides until it covers occupied_tones, then
-    centred in the container in units of four carriers."""
-    s = carriers
+def carrier_map(occupied_tones, container, carriers="FE7F", sink=None):
+    """Subcarrier map of digital_ofdm_mapper_bcv (container = fft_length, ofdm.py:106) or of
+    digital_ofdm_frame_sink (``sink=True``; by default when container == occupied_tones, ofdm.py:240).
+    Both grow the hex string with 'f' on both sides until it covers occupied_tones (a last partial
+    nibble split ceil(diff/2) left, the rest right).  The mapper centres it in the fft_length bins in
+    units of four carriers; the frame sink numbers carrier 4*i + j - diff_left inside the occupied
+    block and reads only the first occupied_tones/4 + diff_left digits."""
+    if sink is None:
+        sink = container == occupied_tones
+    s = carriers or "FE7F"
+    for ch in s:
+        if ch not in "0123456789abcdefABCDEF":
+            raise ValueError("carrier map holds a non-hex digit: %r" % ch)
     diff = occupied_tones - 4 * len(s)
     while diff > 7:
         s = "f" + s + "f"
         diff -= 8
+    dl = 0
     if diff > 0:
         dl = int(math.ceil(diff / 2.0))
         s = "0123456789abcdef"[(1 << dl) - 1] + s
         dr = diff - dl
         s = s + "0123456789abcdef"[0xF ^ ((1 << dr) - 1)]
-    pad = int((container // 4 - len(s)) / 2)  # C integer division (truncates toward zero)
     out = []
-    for i, ch in enumerate(s):
-        if ch not in "0123456789abcdefABCDEF":
-            raise ValueError("carrier map holds a non-hex digit: %r" % ch)
-        v = int(ch, 16)
-        for j in range(4):
-            if (v >> (3 - j)) & 1:
-                out.append(4 * (i + pad) + j)
+    if sink:
+        for i in range(occupied_tones // 4 + dl):
+            v = int(s[i], 16) if i < len(s) else 0
+            for j in range(4):
+                if (v >> (3 - j)) & 1:
+                    out.append(4 * i + j - dl)
+        limit = occupied_tones
+    else:
+        pad = int((container // 4 - len(s)) / 2)  # C integer division (truncates toward zero)
+        for i, ch in enumerate(s):
+            v = int(ch, 16)
+            for j in range(4):
+                if (v >> (3 - j)) & 1:
+                    out.append(4 * (i + pad) + j)
+        limit = container
     if len(out) > occupied_tones:
         raise ValueError("subcarriers allocated exceeds size of occupied carriers")
-    if not out or min(out) < 0 or max(out) >= container:
+    if not out or min(out) < 0 or max(out) >= limit:
         raise ValueError("carrier map leaves no usable data carrier inside the container")
     return out
 
@@ -159,11 +174,13 @@ def make_cfg(options, pad_for_usrp=False, device_ptrs=False, device_id=0, pad_se
     cfg.pad_seed = int(pad_seed)
     if carriers is None:
         carriers = getattr(options, "carrier_map", None)
+    if carriers and len(carriers) > _abi.OFDM_MAX_CARRIER_HEX:
+        raise ValueError("carrier map longer than %d hex digits" % _abi.OFDM_MAX_CARRIER_HEX)
+    # raises ValueError exactly where the blocks' constructors would throw -- or would index outside their
+    # vectors (e.g. occupied_tones = 202: the frame sink's loop reaches carrier 202)
+    carrier_map(occ, N, carriers or "FE7F", sink=False)
+    carrier_map(occ, occ, carriers or "FE7F", sink=True)
     if carriers:
-        if len(carriers) > _abi.OFDM_MAX_CARRIER_HEX:
-            raise ValueError("carrier map longer than %d hex digits" % _abi.OFDM_MAX_CARRIER_HEX)
-        carrier_map(occ, N, carriers)      # raises ValueError exactly where the blocks' ctors would
-        carrier_map(occ, occ, carriers)
         cfg.carrier_map = carriers.encode("ascii")
     return cfg
 

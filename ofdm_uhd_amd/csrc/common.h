@@ -191,45 +191,59 @@ __host__ __device__ __forceinline__ uint32_t pad_symbol_hash(uint64_t seed, uint
   return (uint32_t)((z >> 32) % arity);
 }
 
-// Philox-2x32-10 (Salmon et al., SC'11): counter = sample index, key = stream key
+// Synthetic channel noise (stands in for the radio pair; mirrored by the oracle).  Philox-2x32-10 (Salmon et
+// al., SC'11) keyed by (seed, stream); counter = sample index / 2: one call yields two 32-bit words, word 0 for
+// the even sample of the pair and word 1 for the odd one.  A sample's word gives 16 bits of Box-Muller radius and
+// 16 bits of angle -- plenty for a test channel at 30 dB, and half the integer multiplies of a call per sample.
 __host__ __device__ __forceinline__ uint32_t chan_key(uint64_t seed, uint64_t stream) {
   return (uint32_t)seed ^ (uint32_t)(seed >> 32) ^ ((uint32_t)stream * 0x9E3779B9u + (uint32_t)(stream >> 32) * 0x85EBCA6Bu);
 }
 __device__ __forceinline__ void philox2x32_10(uint32_t& c0, uint32_t& c1, uint32_t k) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
-    c0 = hi ^ k ^ c1;
-    c1 = lo;
+    const uint64_t pr = (uint64_t)0xD256D193u * (uint64_t)c0;  // one v_mad_u64_u32 for both halves
+    c0 = (uint32_t)(pr >> 32) ^ k ^ c1;
+    c1 = (uint32_t)pr;
     k += 0x9E3779B9u;
   }
+}
+// both noise words of the pair that holds sample idx
+__device__ __forceinline__ void chan_pair_words(uint64_t idx, uint32_t key, uint32_t& w_even, uint32_t& w_odd) {
+  const uint64_t pi = idx >> 1;
+  w_even = (uint32_t)pi;
+  w_odd = (uint32_t)(pi >> 32);
+  philox2x32_10(w_even, w_odd, key);
+}
+__device__ __forceinline__ c32 chan_add_noise(c32 x, uint32_t word, float sigma) {
+  const float inv16 = 1.0f / 65536.0f;
+  const float u1 = ((float)(word >> 16) + 0.5f) * inv16;
+  const float u2 = ((float)(word & 0xFFFFu) + 0.5f) * inv16;
+  // Box-Muller on the hardware transcendental units: v_log_f32 (log2), v_sqrt_f32 and v_sin/v_cos_f32, whose
+  // argument is in revolutions -- exactly u2.  A few 1e-7 off libm, scaled by sigma: far below the float32
+  // resolution of the signal it is added to.
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln(u1) = -2 ln2 log2(u1)
+  const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
+  const float s = sigma * 0.70710678118654752440f;
+  x.re = x.re + s * (rad * cs);
+  x.im = x.im + s * (rad * sn);
+  return x;
+}
+__device__ __forceinline__ c32 chan_rotate(c32 x, uint64_t idx, float cfo) {
+  double ph = (double)cfo * (double)idx;
+  ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
+  double s, c;
+  sincos(ph, &s, &c);
+  return cmul(x, mk((float)c, (float)s));
 }
 
 // one channel use: rotate by the carrier offset and add circular Gaussian noise
 __device__ __forceinline__ c32 channel_apply(c32 x, uint64_t idx, float sigma, float cfo, uint64_t seed,
                                              uint64_t stream) {
-  if (cfo != 0.0f) {
-    double ph = (double)cfo * (double)idx;
-    ph = ph - 6.283185307179586476925 * floor(ph / 6.283185307179586476925 + 0.5);
-    double s, c;
-    sincos(ph, &s, &c);
-    x = cmul(x, mk((float)c, (float)s));
-  }
+  if (cfo != 0.0f) x = chan_rotate(x, idx, cfo);
   if (sigma > 0.0f) {
-    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32);
-    philox2x32_10(c0, c1, chan_key(seed, stream));
-    const float inv24 = 1.0f / 16777216.0f;
-    const float u1 = ((float)(c0 >> 8) + 0.5f) * inv24;
-    const float u2 = ((float)(c1 >> 8) + 0.5f) * inv24;
-    // Box-Muller on the hardware transcendental units: v_log_f32 (log2) and v_sin/v_cos_f32, whose
-    // argument is in revolutions -- exactly u2.  A few 1e-7 off libm, scaled by sigma: far below the
-    // float32 resolution of the signal it is added to.
-    // (v_sqrt_f32 like the other three: 1 ulp, against a dozen instructions for the correctly rounded root)
-    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln(u1) = -2 ln2 log2(u1)
-    const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
-    const float s = sigma * 0.70710678118654752440f;
-    x.re = x.re + s * (rad * cs);
-    x.im = x.im + s * (rad * sn);
+    uint32_t we, wo;
+    chan_pair_words(idx, chan_key(seed, stream), we, wo);
+    x = chan_add_noise(x, (idx & 1) ? wo : we, sigma);
   }
   return x;
 }

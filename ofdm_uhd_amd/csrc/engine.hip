@@ -86,11 +86,17 @@ static int ilog2_ceil(unsigned v) {
   return n;
 }
 
-// digital_ofdm_mapper_bcv / digital_ofdm_frame_sink carrier map from a hex string (default
-// "FE7F", transmit_path.py:64): the string is grown with 'f' on both sides until it covers
-// occ carriers (a last partial nibble split left/right), then centred in the container in
-// units of four carriers; MSB of a digit = lowest carrier of its nibble.
-static int build_carrier_map(int occ, int container, const char* carriers, std::vector<int>& map) {
+// digital_ofdm_mapper_bcv / digital_ofdm_frame_sink carrier map from a hex string (default "FE7F",
+// transmit_path.py:64).  Both constructors grow the string with 'f' on both sides until it covers occ carriers
+// (a last partial nibble split ceil(diff/2) left, the rest right); MSB of a digit = lowest carrier of its nibble.
+//   mapper (sink == false): the string is centred in the fft_length bins in units of four carriers --
+//       bin 4*(i + pad) + j, pad = (container/4 - digits)/2;
+//   frame sink (sink == true): carrier 4*i + j - diff_left of the occupied block, diff_left = the carriers the
+//       partial nibble put on the left, over the first occ/4 + diff_left digits only (its loop bound: a longer
+//       string is silently clipped, a missing digit reads as 0).
+// The two agree on the data carriers whenever the mapper's first carrier is bin zeros_on_left; when they do not
+// (a string longer than occ/4 digits, occ % 4 != 0) the reference's own TX and RX disagree and so do these.
+static int build_carrier_map(int occ, int container, const char* carriers, bool sink, std::vector<int>& map) {
   std::vector<int> digits;
   if (occ < 16) return OFDM_E_INVAL;
   if (!carriers || !carriers[0]) carriers = "FE7F";
@@ -109,20 +115,35 @@ static int build_carrier_map(int occ, int container, const char* carriers, std::
     digits.push_back(0xF);
     diff -= 8;
   }
+  int dl = 0;
   if (diff > 0) {
-    const int dl = (diff + 1) / 2, dr = diff - dl;
+    dl = (diff + 1) / 2;
+    const int dr = diff - dl;
     digits.insert(digits.begin(), (1 << dl) - 1);
     digits.push_back(0xF ^ ((1 << dr) - 1));
   }
-  const int pad = (container / 4 - (int)digits.size()) / 2;  // C integer division, as the blocks do
   map.clear();
-  for (size_t i = 0; i < digits.size(); i++)
-    for (int j = 0; j < 4; j++)
-      if ((digits[i] >> (3 - j)) & 1) {
-        int idx = 4 * ((int)i + pad) + j;
-        if (idx < 0 || idx >= container) return OFDM_E_INVAL;
-        map.push_back(idx);
-      }
+  if (sink) {
+    const int nread = occ / 4 + dl;
+    for (int i = 0; i < nread; i++) {
+      const int d = i < (int)digits.size() ? digits[i] : 0;
+      for (int j = 0; j < 4; j++)
+        if ((d >> (3 - j)) & 1) {
+          const int idx = 4 * i + j - dl;
+          if (idx < 0 || idx >= occ) return OFDM_E_INVAL;  // (the block would read outside its input vector)
+          map.push_back(idx);
+        }
+    }
+  } else {
+    const int pad = (container / 4 - (int)digits.size()) / 2;  // C integer division, as the block does
+    for (size_t i = 0; i < digits.size(); i++)
+      for (int j = 0; j < 4; j++)
+        if ((digits[i] >> (3 - j)) & 1) {
+          int idx = 4 * ((int)i + pad) + j;
+          if (idx < 0 || idx >= container) return OFDM_E_INVAL;
+          map.push_back(idx);
+        }
+  }
   if ((int)map.size() > occ) return OFDM_E_INVAL;  // "subcarriers allocated exceeds size of occupied carriers"
   if (map.empty()) return OFDM_E_INVAL;            // no data carrier at all: nothing could ever be sent
   return OFDM_OK;
@@ -205,9 +226,9 @@ extern "C" const char* ofdm_kernel_name(int k) {
 static int apply_carrier_map(ofdm_handle* h, const char* hex) {
   const int N = (int)h->cfg.fft_length, occ = (int)h->cfg.occupied_tones;
   std::vector<int> cmap, smap;
-  if (build_carrier_map(occ, N, hex, cmap) != OFDM_OK)
+  if (build_carrier_map(occ, N, hex, false, cmap) != OFDM_OK)
     FAIL(h, OFDM_E_INVAL, "carrier map: bad hex digit, or subcarriers allocated exceeds size of occupied carriers (mapper)");
-  if (build_carrier_map(occ, occ, hex, smap) != OFDM_OK)
+  if (build_carrier_map(occ, occ, hex, true, smap) != OFDM_OK)
     FAIL(h, OFDM_E_INVAL, "carrier map: bad hex digit, or subcarriers allocated exceeds size of occupied carriers (frame sink)");
   std::vector<int16_t> bin2car(N, (int16_t)-1);
   for (size_t i = 0; i < cmap.size(); i++) bin2car[cmap[i]] = (int16_t)i;

@@ -165,9 +165,9 @@ __device__ __forceinline__ void fft_pass_tw(c32 e[8], int t, const c32* src, c32
 #pragma unroll
       for (int q = 1; q < R; q++) v[q] = cmul_f(v[q], twf.template get<N, LS, R, INV>(k, q));
     }
-    if (R == 8) {
+    if constexpr (R == 8) {
       dft8<INV>(v);
-    } else if (R == 4) {
+    } else if constexpr (R == 4) {
       dft4<INV>(v[0], v[1], v[2], v[3]);
     } else {
       dft2(v[0], v[1]);

@@ -797,6 +797,7 @@ struct RxState {
       partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
       out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, stash_peaks, stash_P, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
+  uint64_t origin = 0;  // index, in its capture, of the first sample of the ofdm_rx calls (ofdm_rx_set_origin)
   std::vector<uint64_t> last_pos;  // host copy: flag sample of every packet of the last call
   // chunked streams (ofdm_rx_set_flag_history): flags settled by earlier calls replace whatever this call
   // detects up to trust_after; the NCO line of the flag before them

@@ -50,6 +50,7 @@ struct SyncParams {
   int B;          // outputs per block = F - ntaps + 1
   int ntm1;       // ntaps - 1 = F - B
   int R;          // samples in the LDS ring of y (multiple of 8)
+  int goff;       // the filter's blocks start at samples m*B - goff (goff in [0, B)): grid of the capture's first sample
   int tiles_per_seg, nwarm;
   int exact_all;  // metric tap: evaluate every sample in fixed point
   int ablate;     // diagnostic build only (-DSYNC_DIAG, see SYNC_ABLATE): 1 skip the filter transforms, 2 skip metric, 4 skip y store
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   unsigned long long cand_base = 0, piece_base = 0;
   uint32_t cand_left = 0, piece_left = 0;
   // filter front: first sample of the next block to transform; the ring slot of the tile's first sample
-  uint64_t fbs = (ws / (uint64_t)B) * (uint64_t)B;
+  int64_t fbs = (int64_t)(((ws + (uint64_t)p.goff) / (uint64_t)B) * (uint64_t)B) - (int64_t)p.goff;
   int rbase = 0;
   // per-thread constants of the filter transforms (a thread keeps its place t in its block for the whole kernel):
   // its twiddles of both radix-8 passes, its 8 bins of the transformed taps; and the input window of the NEXT
@@ -462,7 +463,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #pragma unroll
   for (int m = 0; m < 8; m++) Hr[m] = p.Hf[tF + m * TF];
   {
-    const int64_t x0 = (int64_t)fbs + (int64_t)gF * B - ntm1 + tF;
+    const int64_t x0 = fbs + (int64_t)gF * B - ntm1 + tF;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       const int64_t xi = x0 + m * TF;
@@ -485,17 +486,17 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     //         round overwrites slots whose samples lie more than HY before this tile -- every read of them
     //         happened before the last barrier of the previous iteration; the transforms' scratch overlays
     //         mt / me / ue, which are dead by then for the same reason.
-    while (fbs < t0 + (uint64_t)T) {
+    while (fbs < t0s + T) {
       const int g = tl / TF, t = tl % TF;
       c32* sc = fsc + g * fft_lds_points(F);
-      const int64_t bs = (int64_t)fbs + (int64_t)g * B;  // first output sample of this thread's block
+      const int64_t bs = fbs + (int64_t)g * B;  // first output sample of this thread's block
       c32 e[8];
 #pragma unroll
       for (int m = 0; m < 8; m++) e[m] = xn[m];
       STAMP_VM(0);
-      fbs += (uint64_t)BPR * (uint64_t)B;
+      fbs += (int64_t)BPR * B;
       {
-        const int64_t x0 = (int64_t)fbs + (int64_t)g * B - ntm1 + t;
+        const int64_t x0 = fbs + (int64_t)g * B - ntm1 + t;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const int64_t xi = x0 + m * TF;
@@ -520,9 +521,11 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
       STAMP(13);
       const int rel0 = rbase + (int)(bs - t0s) - ntm1 + t;  // ring-relative position of transform point t
+      // (a capture's first block may start before its first sample: y before the stream stays zero)
+      const int first = ntm1 + ((bs < 0) ? (int)(-bs) : 0);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
-        if (t + m * TF >= ntm1) ys[sync_lp(ring_wrap(rel0 + m * TF, R))] = e[m];
+        if (t + m * TF >= first) ys[sync_lp(ring_wrap(rel0 + m * TF, R))] = e[m];
       }
     }
     STAMP(1);

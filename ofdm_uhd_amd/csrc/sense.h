@@ -77,17 +77,22 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
 #pragma unroll
       for (int m = 0; m < 8; m++) nx[m] = ln ? src[t + m * TPT] : mk(0.f, 0.f);
     }
-    fft_run<NS, false>(e, t, my, p.tw, [] { __syncthreads(); });
+    if constexpr (TPT <= WAVE) {
+      fft_run<NS, false>(e, t, my, p.tw, FftWaveSync());
+    } else {
+      fft_run<NS, false>(e, t, my, p.tw, FftBlockSync());
+    }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
       float pw = e[m].re * e[m].re + e[m].im * e[m].im;  // complex_to_mag_squared
       mx[m] = (live && pw > mx[m]) ? pw : mx[m];          // accrue_stats
     }
-    __syncthreads();  // LDS scratch is reused by the next round
+    if constexpr (TPT > WAVE) __syncthreads();  // LDS scratch is reused by the next round (wave-private up to NS = 512)
   }
   // fold the G groups: bin b of group g at fl[g*NS + b]
   float* fl = reinterpret_cast<float*>(smem_raw);
   if (G > 1) {
+    __syncthreads();  // every group is done with its transform scratch, which fl overlays
 #pragma unroll
     for (int m = 0; m < 8; m++) fl[g * NS + t + m * TPT] = mx[m];
     __syncthreads();

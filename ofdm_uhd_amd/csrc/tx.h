@@ -274,27 +274,82 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
     for (int m = 0; m < 8; m++) freq_tap[sym * N + ((t + m * T + N / 2) & (N - 1))] = e[m];
   }
 
-  fft_run<N, true>(e, t, lds, p.tw, [] { __syncthreads(); });
+  // up to N = 512 a symbol's N/8 threads sit inside one wave: no workgroup barrier in the exchanges
+  if constexpr (T <= WAVE) {
+    fft_run<N, true>(e, t, lds, p.tw, FftWaveSync());
+  } else {
+    fft_run<N, true>(e, t, lds, p.tw, FftBlockSync());
+  }
 
   if (!active) return;
   const uint64_t base = lead + sym * (uint64_t)p.L;
   c32* o = out + base;
+  c32 v[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    v[m] = e[m];
+    v[m].re = v[m].re * p.scale1;
+    v[m].im = v[m].im * p.scale1;
+    v[m].re = v[m].re * p.amp;
+    v[m].im = v[m].im * p.amp;
+  }
+  if (!p.chan_on) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int n = t + m * T;
+      o[p.CP + n] = v[m];
+      if (n >= N - p.CP) o[n - (N - p.CP)] = v[m];  // ofdm_cyclic_prefixer: out[0:CP] = in[N-CP:N]
+    }
+    return;
+  }
+  // ---- synthetic channel fused into the store -------------------------------------------------------------
+  // Noise words come in pairs (even, odd stream position).  When the symbol starts on an even position and CP is
+  // even, lanes t and t^1 hold the two samples of a pair for every m: the even lane draws the pairs of the even
+  // m, the odd lane those of the odd m, and they swap the halves they do not need (one DPP move).
+  const uint32_t key = chan_key(p.seed, p.stream);
+  const bool paired = p.sigma > 0.0f && (((base + (uint64_t)p.CP) | (uint64_t)p.CP) & 1ull) == 0;
+  uint32_t wb[8], wc[8];  // noise words of the body samples / of their cyclic-prefix copies
+  if (paired) {
+    const int odd = t & 1;
+#pragma unroll
+    for (int mm = 0; mm < 4; mm++) {
+      const int mine = 2 * mm + odd;
+      const int n = t + mine * T;
+      uint32_t we, wo;
+      chan_pair_words(base + (uint64_t)(p.CP + n), key, we, wo);
+      const uint32_t keep = odd ? wo : we, give = odd ? we : wo;
+      const uint32_t got = (uint32_t)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+      wb[2 * mm] = odd ? got : keep;
+      wb[2 * mm + 1] = odd ? keep : got;
+      uint32_t ce = 0, co = 0;
+      if (n >= N - p.CP) chan_pair_words(base + (uint64_t)(n - (N - p.CP)), key, ce, co);
+      const uint32_t ckeep = odd ? co : ce, cgive = odd ? ce : co;
+      const uint32_t cgot = (uint32_t)__builtin_amdgcn_mov_dpp((int)cgive, 0xB1, 0xF, 0xF, true);
+      wc[2 * mm] = odd ? cgot : ckeep;
+      wc[2 * mm + 1] = odd ? ckeep : cgot;
+    }
+  }
 #pragma unroll
   for (int m = 0; m < 8; m++) {
     const int n = t + m * T;
-    c32 v = e[m];
-    v.re = v.re * p.scale1;
-    v.im = v.im * p.scale1;
-    v.re = v.re * p.amp;
-    v.im = v.im * p.amp;
     const int pos = p.CP + n;
-    c32 a = v;
-    if (p.chan_on) a = channel_apply(v, base + (uint64_t)pos, p.sigma, p.cfo, p.seed, p.stream);
+    c32 a = v[m];
+    if (paired) {
+      if (p.cfo != 0.0f) a = chan_rotate(a, base + (uint64_t)pos, p.cfo);
+      a = chan_add_noise(a, wb[m], p.sigma);
+    } else {
+      a = channel_apply(v[m], base + (uint64_t)pos, p.sigma, p.cfo, p.seed, p.stream);
+    }
     o[pos] = a;
     if (n >= N - p.CP) {  // ofdm_cyclic_prefixer: out[0:CP] = in[N-CP:N]
       const int pc = n - (N - p.CP);
-      c32 b = v;
-      if (p.chan_on) b = channel_apply(v, base + (uint64_t)pc, p.sigma, p.cfo, p.seed, p.stream);
+      c32 b = v[m];
+      if (paired) {
+        if (p.cfo != 0.0f) b = chan_rotate(b, base + (uint64_t)pc, p.cfo);
+        b = chan_add_noise(b, wc[m], p.sigma);
+      } else {
+        b = channel_apply(v[m], base + (uint64_t)pc, p.sigma, p.cfo, p.seed, p.stream);
+      }
       o[pc] = b;
     }
   }

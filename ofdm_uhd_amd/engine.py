@@ -91,6 +91,7 @@ class Engine(object):
         carrier map of BOTH directions of this engine, e.g. to hex_conv's output clipped to
         occupied_tones/4 digits (sensing_and_tramsmitting.py:470)."""
         self._check(self._lib.ofdm_set_carrier_map(self._h, (carriers or "").encode("ascii")))
+        self.cfg.carrier_map = (carriers or "").encode("ascii")   # the host copy follows the handle (stream geometry)
 
     def set_channel(self, sigma=0.0, cfo=0.0, seed=0xC0FFEE, stream_id=0, lead=0, tail=0, enable=True):
         if not enable:
@@ -249,6 +250,11 @@ class Engine(object):
         if k:
             self._check(self._lib.ofdm_rx_nco_state(self._h, _ptr(fl), _ptr(phi), _ptr(st), _ptr(sw), k, C.byref(n)))
         return fl[:k], phi[:k], st[:k], sw[:k]
+
+    def set_origin(self, first_sample_index=0):
+        """Index, in its capture, of the first sample of the following rx() calls: keeps the channel
+        filter's block grid where one call on the whole capture would have it."""
+        self._check(self._lib.ofdm_rx_set_origin(self._h, int(first_sample_index)))
 
     def set_flag_history(self, flags=None, steps=None, swallowed=None, trust_after=-1, pred=(0, 0, 0.0)):
         """The settled past for the following rx() calls (flags=None switches it off): ``flags`` /

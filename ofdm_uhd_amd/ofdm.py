@@ -232,6 +232,7 @@ class ofdm_demod(object):
         # the NCO idles at phase 0
         self._s_hist = [(0, 0, 0.0, 0)]
         self._engine.set_flag_history(None)
+        self._engine.set_origin(0)
         self._streaming = False
 
     def feed(self, iq, flush=False):
@@ -254,6 +255,7 @@ class ofdm_demod(object):
             pred = before[-1] if before else (0, 0, 0.0, 0)
             eng.set_flag_history([f[0] - base for f in inside], [f[2] for f in inside], [f[3] for f in inside],
                                  trust_after=self._s_final - base, pred=(pred[0] - base, pred[1], pred[2]))
+            eng.set_origin(base)
             pkts = eng.rx(buf)
             pos = eng.rx_packet_pos().astype(np.int64) + base
             for (ok, payload), p in zip(pkts, pos):

@@ -245,7 +245,10 @@ int orc_unmake_packet(const ofdm_cfg *cfg, const uint8_t *msg, uint32_t len, uin
  * (transmit_path.py:64 default, reset_carrier_map commented out :67); any other
  * hex string (cfg->carrier_map) goes through the same growth / centring rule.  */
 /* ------------------------------------------------------------------------ */
-int orc_carrier_map(int occ, int container, const char *carriers, int *map, int cap) {
+/* sink = 0: digital_ofdm_mapper_bcv's rule (bin 4*(i+pad)+j of the fft_length bins [A.1]);
+ * sink = 1: digital_ofdm_frame_sink's rule (carrier 4*i + j - diff_left of the occupied block, over the first
+ *           occ/4 + diff_left digits -- its constructor's loop bound [A.10]).                                  */
+int orc_carrier_map2(int occ, int container, const char *carriers, int sink, int *map, int cap) {
   /* hex digit values, MSB = lowest carrier of the nibble */
   int digits[OFDM_MAX_CARRIER_HEX + OFDM_MAX_FFT / 4 + 8];
   int nd = 0;
@@ -280,19 +283,38 @@ int orc_carrier_map(int occ, int container, const char *carriers, int *map, int 
   }
   for (int i = 0; i < nf; i++) digits[nd++] = 0xF;
   if (have_extra) digits[nd++] = 0xF ^ ((1 << dr) - 1);
-  int pad = (container / 4 - nd) / 2; /* C integer division, as the C++ does */
   int n = 0;
-  for (int i = 0; i < nd; i++)
-    for (int j = 0; j < 4; j++)
-      if ((digits[i] >> (3 - j)) & 1) {
-        int idx = 4 * (i + pad) + j;
-        if (idx < 0 || idx >= container) return OFDM_E_INVAL;
-        if (n >= cap) return OFDM_E_CAPACITY;
-        map[n++] = idx;
-      }
+  if (sink) {
+    /* for(i = 0; i < (d_occupied_carriers/4)+diff_left; i++) ... push_back(4*i + j - diff_left) */
+    int nread = occ / 4 + dl;
+    for (int i = 0; i < nread; i++) {
+      int d = i < nd ? digits[i] : 0; /* past the end of the string: strtol of the terminator = 0 */
+      for (int j = 0; j < 4; j++)
+        if ((d >> (3 - j)) & 1) {
+          int idx = 4 * i + j - dl;
+          if (idx < 0 || idx >= occ) return OFDM_E_INVAL;
+          if (n >= cap) return OFDM_E_CAPACITY;
+          map[n++] = idx;
+        }
+    }
+  } else {
+    int pad = (container / 4 - nd) / 2; /* C integer division, as the C++ does */
+    for (int i = 0; i < nd; i++)
+      for (int j = 0; j < 4; j++)
+        if ((digits[i] >> (3 - j)) & 1) {
+          int idx = 4 * (i + pad) + j;
+          if (idx < 0 || idx >= container) return OFDM_E_INVAL;
+          if (n >= cap) return OFDM_E_CAPACITY;
+          map[n++] = idx;
+        }
+  }
   if (n > occ) return OFDM_E_INVAL; /* "subcarriers allocated exceeds size of occupied carriers" */
   if (n == 0) return OFDM_E_INVAL;
   return n;
+}
+/* test-suite convention: container == occupied_tones asks for the frame sink's map */
+int orc_carrier_map(int occ, int container, const char *carriers, int *map, int cap) {
+  return orc_carrier_map2(occ, container, carriers, container == occ, map, cap);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -593,7 +615,7 @@ int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload
   int nbits = orc_nbits(cfg);
   if (occ > N) return OFDM_E_INVAL; /* mapper ctor: occupied_carriers > fft_length */
   int *map = (int *)malloc(sizeof(int) * (size_t)occ);
-  int nc = orc_carrier_map(occ, N, cfg->carrier_map, map, occ);
+  int nc = orc_carrier_map2(occ, N, cfg->carrier_map, 0, map, occ);
   if (nc < 0) {
     free(map);
     return nc;
@@ -672,7 +694,9 @@ int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload
 /* ------------------------------------------------------------------------ */
 /* synthetic channel (stands in for the UHD sink/source pair)                */
 /* ------------------------------------------------------------------------ */
-/* Philox-2x32-10 (Salmon et al., SC'11): counter = sample index, key = stream key */
+/* Philox-2x32-10 (Salmon et al., SC'11), key = stream key.  The channel draws one call per PAIR of samples
+ * (counter = sample index / 2): word 0 serves the even sample, word 1 the odd one; a sample's word gives 16 bits
+ * of Box-Muller radius and 16 bits of angle. */
 static inline uint32_t chan_key(uint64_t seed, uint64_t stream) {
   return (uint32_t)seed ^ (uint32_t)(seed >> 32) ^ ((uint32_t)stream * 0x9E3779B9u + (uint32_t)(stream >> 32) * 0x85EBCA6Bu);
 }
@@ -690,7 +714,7 @@ void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[2]) {
 }
 
 int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0) {
-  const float inv24 = 1.0f / 16777216.0f;
+  const float inv16 = 1.0f / 65536.0f;
   for (uint64_t i = 0; i < n; i++) {
     uint64_t idx = index0 + i;
     ofdm_c32 x = iq[i];
@@ -702,9 +726,10 @@ int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0) 
     }
     if (ch->sigma > 0.0f) {
       uint32_t r[2];
-      orc_philox(ch->seed, ch->stream_id, idx, r);
-      float u1 = ((float)(r[0] >> 8) + 0.5f) * inv24;
-      float u2 = ((float)(r[1] >> 8) + 0.5f) * inv24;
+      orc_philox(ch->seed, ch->stream_id, idx >> 1, r);
+      uint32_t word = r[idx & 1];
+      float u1 = ((float)(word >> 16) + 0.5f) * inv16;
+      float u2 = ((float)(word & 0xFFFFu) + 0.5f) * inv16;
       float rad = sqrtf(-2.0f * logf(u1));
       float th = 6.28318530717958647692f * u2;
       float s = ch->sigma * 0.70710678118654752440f;
@@ -1101,7 +1126,7 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   sk->occ = occ;
   sk->lanes = N / 8;
   memcpy(sk->pos, cfg->constellation, sizeof(ofdm_c32) * cfg->arity);
-  sk->nmap = orc_carrier_map(occ, occ, cfg->carrier_map, sk->map, OFDM_MAX_FFT);
+  sk->nmap = orc_carrier_map2(occ, occ, cfg->carrier_map, 1, sk->map, OFDM_MAX_FFT);
   sk->phase_gain = cfg->phase_gain;
   sk->freq_gain = cfg->freq_gain;
   sk->eq_gain = cfg->eq_gain;

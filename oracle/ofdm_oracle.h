@@ -27,6 +27,7 @@ int orc_make_packet(const ofdm_cfg *cfg, const uint8_t *payload, uint32_t len, u
 int orc_unmake_packet(const ofdm_cfg *cfg, const uint8_t *msg, uint32_t len, uint8_t *payload_out,
                       uint32_t *payload_len, int *ok);
 int orc_carrier_map(int occ, int container, const char *carriers, int *map, int cap);
+int orc_carrier_map2(int occ, int container, const char *carriers, int sink, int *map, int cap);
 uint32_t orc_tx_data_symbols(const ofdm_cfg *cfg, uint32_t framed_len, int ncarriers);
 uint32_t orc_pad_symbol(uint64_t seed, uint64_t pkt, uint64_t slot, uint32_t arity);
 int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload_off, const uint32_t *payload_len,

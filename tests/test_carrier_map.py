@@ -37,9 +37,9 @@ def test_host_and_oracle_agree_on_every_recorded_map(orc, sensed):
 
 def test_short_maps_grow_with_f(orc):
     # "FFFFFE7FFFFFF" (sensing_and_tramsmitting.py:461): 13 digits = 52 carriers.  Grown to 200
-    # occupied tones it becomes 51 digits whose last two carriers fall outside a 200-carrier
-    # container (GNU Radio would index past its vector there): both sides refuse such maps,
-    # as they refuse occupied_tones that are not a multiple of four with the default string.
+    # occupied tones it becomes 51 digits; the frame sink reads occ/4 + diff_left = 52 of them and
+    # numbers the carriers from -diff_left: host mirror and oracle agree wherever the map is legal
+    # and refuse the same ones.
     accepted = refused = 0
     for c in ("FFFFFE7FFFFFF", "0", "A5", "fe7f"):
         for occ, N in ((200, 512), (120, 256), (1200, 2048), (50, 64)):
@@ -55,6 +55,42 @@ def test_short_maps_grow_with_f(orc):
                 accepted += 1
     assert accepted >= 20 and refused >= 1
     assert len(config.carrier_map(204, 512, "FFFFFE7FFFFFF")) == 202
+
+
+@pytest.mark.parametrize("mod,N,occ,CP", [("qpsk", 512, 180, 128), ("bpsk", 128, 100, 32), ("qpsk", 256, 204, 64)])
+def test_occupied_tones_not_a_multiple_of_eight(orc, mod, N, occ, CP):
+    """occ - 16 not a multiple of 8: the constructors add a partial nibble on each side.  The mapper centres the grown
+    string in the fft_length bins, the frame sink numbers its carriers 4*i + j - diff_left inside the occupied block:
+    the same carriers, so the loopback works (it must: the reference runs such sizes).  Host mirror, oracle and the
+    float64 model agree."""
+    import np_model as npm
+    m, s = config.carrier_map(occ, N), config.carrier_map(occ, occ)
+    zl = (N - occ + 1) // 2
+    assert [c - zl for c in m] == s and s[0] == 0 and len(s) == occ - 2
+    assert orc.carrier_map(occ, N).tolist() == m and orc.carrier_map(occ, occ).tolist() == s
+    cfg = make_cfg(mod, N, occ, CP)
+    pay = make_payloads(3, 200, seed=occ)
+    x = loopback_stream(orc, cfg, pay, snr_db=30.0)
+    r = orc.rx(cfg, x)
+    assert r.packets == [(True, p) for p in pay]
+    assert npm.rx(cfg, x)["packets"] == r.packets
+
+
+def test_frame_sink_reads_occ_over_four_digits(orc):
+    """digital_ofdm_frame_sink's constructor loop stops after occupied_tones/4 + diff_left digits: a longer string is
+    clipped (sensing_and_tramsmitting.py:470 clips its 64-digit map to occ/4 itself), and a size whose grown string
+    reaches past the occupied block (occ = 202: carrier 202) is refused where GNU Radio would read outside its
+    input vector."""
+    long = "F" * 10 + "FE7F" + "0" * 50                   # 64 digits
+    assert config.carrier_map(200, 200, long) == config.carrier_map(200, 200, long[:50])
+    assert orc.carrier_map(200, 200, long).tolist() == config.carrier_map(200, 200, long[:50])
+    for bad in (202, 50):
+        with pytest.raises(ValueError):
+            config.carrier_map(bad, bad)
+        with pytest.raises(ValueError):
+            orc.carrier_map(bad, bad)
+    with pytest.raises(ValueError):
+        make_cfg("qpsk", 512, 202, 128)
 
 
 def test_illegal_maps(orc, sensed):

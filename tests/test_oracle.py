@@ -115,7 +115,7 @@ def test_sampler_timeout_path(orc):
     packet: the closed form used on the GPU must agree with the automaton."""
     cfg = make_cfg("qpsk", 64, 48, 16)
     N, CP = 64, 16
-    pay = make_payloads(2, 60, seed=5)
+    pay = make_payloads(2, 60, seed=6)
     a = orc.tx(cfg, pay[:1], lead=2 * N, tail=0)
     gap = np.zeros(1100 * (N + CP) + 37, np.complex64)
     b = orc.tx(cfg, pay[1:], lead=0, tail=(N + CP) + 2 * N)
