@@ -91,10 +91,11 @@ __host__ __device__ inline int sync_filter_F(int ntaps) {
   const int f = 2 * p2;
   return f < 64 ? 64 : f;
 }
-// ring of y: the history a tile's metric looks back on, the tile, and what a round of transforms may run ahead
+// ring of y: the history a tile's metric looks back on, the tile, and what a round of blocks may run ahead
+// (a round starts while fewer than a tile's samples are ready and adds bpr * B of them)
 __host__ __device__ inline int sync_ring_samples(int HY, int F, int B) {
   const int bpr = SYNC_THREADS / (F / 8);
-  return (HY + SYNC_TILE + (bpr - 1) * B + F + 7) / 8 * 8;
+  return (HY + SYNC_TILE + bpr * B + 7) / 8 * 8;
 }
 
 struct SyncLds {
@@ -486,6 +487,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     //         round overwrites slots whose samples lie more than HY before this tile -- every read of them
     //         happened before the last barrier of the previous iteration; the transforms' scratch overlays
     //         mt / me / ue, which are dead by then for the same reason.
+    // issue priority: the metric phase below is a chain of short steps between workgroup barriers, each as slow as
+    // its slowest wave; the transforms are long, dense and barrier-free.  Waves in the metric phase go first, the
+    // co-resident workgroup's transforms fill the gaps (measured: -1 %).
+    __builtin_amdgcn_s_setprio(0);
     while (fbs < t0s + T) {
       const int g = tl / TF, t = tl % TF;
       c32* sc = fsc + g * fft_lds_points(F);
@@ -529,6 +534,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
     }
     STAMP(1);
+    __builtin_amdgcn_s_setprio(2);
     __syncthreads();  // B2: the tile's y is in the ring
     STAMP(2);
     const int ybs = ring_wrap(rbase + SYNC_V * tl, R);
