@@ -28,7 +28,7 @@ OFDM_F_PAD_FOR_USRP = 1 << 1
 (TAP_TX_PACKETS, TAP_TX_FREQ, TAP_RX_CHAN_FILT, TAP_RX_METRIC, TAP_RX_PEAKS, TAP_RX_ANGLES,
  TAP_RX_FRAMES, TAP_RX_FFT, TAP_RX_ACQ, TAP_RX_SINK, TAP_RX_PACKETS, TAP_COUNT) = range(12)
 
-(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_COUNT) = range(9)
+(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_COUNT) = range(10)
 OFDM_SENSE_MAX_FFT = 4096
 
 

@@ -28,7 +28,9 @@
 #include "common.h"
 #include "fft.h"
 
+#ifndef SYNC_THREADS
 #define SYNC_THREADS 256
+#endif
 #define SYNC_V 8                            // consecutive samples per thread
 #define SYNC_TILE (SYNC_THREADS * SYNC_V)   // 2048 samples per tile
 #define SYNC_GUARD 1.0e-3f                  // guard band of the float32 pre-selection
@@ -46,24 +48,17 @@ struct SyncParams {
   int N, D, CP;
   int HY;         // y history the metric needs before a tile (2*D + CP, multiple of 8)
   int HM;         // M history (CP)
-  int F;          // channel filter: transform length of the overlap-save blocks (gr_fft_filter_ccc's choice)
-  int B;          // outputs per block = F - ntaps + 1
-  int ntm1;       // ntaps - 1 = F - B
   int R;          // samples in the LDS ring of y (multiple of 8)
-  int goff;       // the filter's blocks start at samples m*B - goff (goff in [0, B)): grid of the capture's first sample
   int tiles_per_seg, nwarm;
   int exact_all;  // metric tap: evaluate every sample in fixed point
-  int ablate;     // diagnostic build only (-DSYNC_DIAG, see SYNC_ABLATE): 1 skip the filter transforms, 2 skip metric, 4 skip y store
+  int ablate;     // diagnostic build only (-DSYNC_DIAG, see SYNC_ABLATE): 2 skip metric
   unsigned long long* stamps;  // diagnostic build (-DSYNC_STAMPS): [wg][12] cycles per phase of wave 0
   uint64_t nsamples, ntiles;
   float tapcp;       // float(1/CP)
   float cand_thr;    // -max(rise, fall)
   float alpha;       // peak detector alpha
   double decay;      // double(1.0f - alpha)
-  const c32* x;
-  c32* y;
-  const c32* Hf;      // [F] transform of the taps, scaled by 1/F
-  const c32* twF;     // [F] exp(-2 pi i k / F)
+  const c32* y;       // filtered stream (k_chan_filter's output)
   float* metric_tap;  // optional [nsamples]
   // outputs
   double* tile_B;          // [ntiles] zero-init running average over the tile
@@ -91,19 +86,92 @@ __host__ __device__ inline int sync_filter_F(int ntaps) {
   const int f = 2 * p2;
   return f < 64 ? 64 : f;
 }
-// ring of y: the history a tile's metric looks back on, the tile, and what a round of blocks may run ahead
-// (a round starts while fewer than a tile's samples are ready and adds bpr * B of them)
-__host__ __device__ inline int sync_ring_samples(int HY, int F, int B) {
-  const int bpr = SYNC_THREADS / (F / 8);
-  return (HY + SYNC_TILE + bpr * B + 7) / 8 * 8;
+// ring of y in k_sync's LDS: the history a tile's metric looks back on and the tile itself
+__host__ __device__ inline int sync_ring_samples(int HY) { return (HY + SYNC_TILE + 7) / 8 * 8; }
+
+// ---------------------------------------------------------------------------------
+// Channel filter = gr_fft_filter_ccc(1, taps) (ofdm_receiver.py~:76,131) the way GNU Radio runs it [SURVEY A.5]:
+// overlap-save blocks of B = F - ntaps + 1 outputs on the grid m*B of the capture; block b transforms the F samples
+// x[b*B - (ntaps-1) .. b*B + B), multiplies by the transformed taps (scaled 1/F) and keeps the last B points of
+// the inverse transform.  One block = F/8 threads (one wave at F = 512), 8 points per thread in registers, the two
+// exchanges of each transform through a private LDS scratch (no workgroup barrier up to F = 512); a workgroup runs
+// 256/(F/8) blocks side by side and walks the stream round by round, the next round's window in flight while the
+// current one is transformed.  A thread keeps its place in its block for the whole kernel, so its twiddles and its
+// bins of the transformed taps live in registers.  Streaming: 8 B in + 8 B out per sample, 4.6 KB of LDS per wave.
+// The transform schedule is fft.h's (the oracle runs the identical schedule: y is bit-exact).
+// ---------------------------------------------------------------------------------
+struct FilterParams {
+  int B;       // outputs per block = F - ntaps + 1
+  int ntm1;    // ntaps - 1 = F - B
+  int goff;    // blocks start at samples m*B - goff (goff in [0, B)): grid of the capture's first sample (ofdm_rx_set_origin)
+  uint64_t nsamples, nrounds;
+  const c32* x;
+  c32* y;
+  const c32* Hf;   // [F] transform of the taps, scaled by 1/F
+  const c32* twF;  // [F] exp(-2 pi i k / F)
+};
+
+template <int F>
+__global__ void __launch_bounds__(256, 3) k_chan_filter(FilterParams p) {
+  constexpr int TF = F / 8;     // threads per block of the filter
+  constexpr int BPR = 256 / TF; // blocks per round of a workgroup
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int g = tid / TF, t = tid % TF;
+  c32* sc = reinterpret_cast<c32*>(smem) + g * fft_lds_points(F);
+  const int B = p.B, ntm1 = p.ntm1;
+  FftTwRegs<F> twr;
+  twr.load(p.twF, t);
+  c32 Hr[8], xn[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) Hr[m] = p.Hf[t + m * TF];
+  // first output sample of this thread's block in round r: (r * BPR + g) * B - goff
+  uint64_t r = blockIdx.x;
+  auto load_window = [&](uint64_t rr) {
+    const int64_t x0 = (int64_t)((rr * BPR + (uint64_t)g) * (uint64_t)B) - p.goff - ntm1 + t;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int64_t xi = x0 + m * TF;
+      xn[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
+    }
+  };
+  if (r < p.nrounds) load_window(r);
+  for (; r < p.nrounds; r += gridDim.x) {
+    c32 e[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) e[m] = xn[m];
+    if (r + gridDim.x < p.nrounds) load_window(r + gridDim.x);
+    // Opaque copy of the thread's place in its block, renewed every round: otherwise the compiler hoists the
+    // LDS addresses of all passes out of the loop (~40 registers) and spills.
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    if constexpr (TF <= WAVE) {
+      fft_run1<F, false>(e, tt, sc, twr, FftWaveSync());
+    } else {
+      fft_run1<F, false>(e, tt, sc, twr, FftBlockSync());
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) e[m] = cmul(e[m], Hr[m]);  // volk_32fc_x2_multiply_32fc
+    asm volatile("" : "+v"(tt));
+    if constexpr (TF <= WAVE) {
+      fft_run1<F, true>(e, tt, sc, twr, FftWaveSync());
+    } else {
+      fft_run1<F, true>(e, tt, sc, twr, FftBlockSync());
+    }
+    const int64_t bs = (int64_t)((r * BPR + (uint64_t)g) * (uint64_t)B) - p.goff;  // first output of the block
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int64_t n = bs + (t + m * TF - ntm1);
+      if (t + m * TF >= ntm1 && n >= 0 && (uint64_t)n < p.nsamples) p.y[n] = e[m];
+    }
+  }
 }
 
 struct SyncLds {
   size_t ys, work, mt, me, ue, mh, misc, total;
 };
-// LDS: the ring of filtered samples | a work area that is the transforms' scratch during the filter phase and
-// holds the tile's M values (mt; later the exact u, ue) and -- rare path -- the exact M (me) during the metric
-// phase | the CP newest M values of the previous tile (mh) | scan / vote scratch.
+// LDS: the ring of filtered samples | the tile's M values (mt; later the exact u, ue) and -- rare path -- the
+// exact M (me) | the CP newest M values of the previous tile (mh) | scan / vote scratch.
 __host__ __device__ inline SyncLds sync_lds_layout(int R, int HM, int CP) {
   SyncLds l;
   size_t o = 0;
@@ -116,9 +184,7 @@ __host__ __device__ inline SyncLds sync_lds_layout(int R, int HM, int CP) {
   const size_t mt_bytes = ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
   const size_t me_bytes = ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
   l.me = o + mt_bytes;  // exact M over [amin-CP+1, bmax]
-  const size_t fft_bytes = (size_t)SYNC_THREADS * 9 * sizeof(c32);  // (256 / (F/8)) transforms x (F + F/8) points, any F
-  const size_t work_bytes = mt_bytes + me_bytes > fft_bytes ? mt_bytes + me_bytes : fft_bytes;
-  o += work_bytes;
+  o += mt_bytes + me_bytes;
   l.mh = o;  // M history: the CP values before the tile
   o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
   l.misc = o;
@@ -389,16 +455,9 @@ __device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* u
 #else
 #define SYNC_ABLATE(p, bit) 0
 #endif
-// F: transform length of the channel filter's overlap-save blocks.  W: workgroups per CU the register allocation
-// aims at -- 3 when the LDS footprint allows three, else 2.
-//
-// Channel filter = gr_fft_filter_ccc(1, taps) (ofdm_receiver.py~:76,131) the way GNU Radio runs it: blocks of
-// B = F - ntaps + 1 outputs on the grid b*B of the stream; block b transforms the F samples x[b*B - (ntaps-1) ..
-// b*B + B), multiplies by the transformed taps (scaled 1/F) and keeps the last B points of the inverse
-// transform.  One block = F/8 threads (one wave at F = 512), 8 points per thread in registers, exchanges through
-// a private LDS scratch, no workgroup barrier inside a round; a round = 256/(F/8) blocks side by side.  The
-// transform schedule is fft.h's (the oracle runs the identical schedule: y is bit-exact).
-template <int F, int W>
+// W: workgroups per CU the register allocation aims at -- 3 when the LDS footprint allows three, else 2 (long
+// symbols: the y history alone is N+CP samples).
+template <int W>
 __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -407,12 +466,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   constexpr int T = SYNC_TILE;
-  constexpr int TF = F / 8;               // threads per filter block
-  constexpr int BPR = SYNC_THREADS / TF;  // filter blocks per round
   const int R = p.R;
   const SyncLds L = sync_lds_layout(R, p.HM, p.CP);
   c32* ys = reinterpret_cast<c32*>(smem + L.ys);
-  c32* fsc = reinterpret_cast<c32*>(smem + L.work);
   float* mh = reinterpret_cast<float*>(smem + L.mh);
   float* mt = reinterpret_cast<float*>(smem + L.mt);
   float* me = reinterpret_cast<float*>(smem + L.me);
@@ -438,7 +494,6 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   const int64_t qvalid = warm ? (int64_t)(ws + (uint64_t)p.D) : 0;
   const int64_t mvalid = warm ? (int64_t)(ws + 2ull * (uint64_t)p.D) - 1 : 0;
   const int D = p.D, CP = p.CP, HM = p.HM;
-  const int B = p.B, ntm1 = p.ntm1;
   const float inv_cp = 1.0f / (float)CP;
 
   // ---- segment prologue: the ring (y before the stream start reads as zero) and the M history ----
@@ -451,26 +506,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   // current allocation chunks of this workgroup (uniform across the block)
   unsigned long long cand_base = 0, piece_base = 0;
   uint32_t cand_left = 0, piece_left = 0;
-  // filter front: first sample of the next block to transform; the ring slot of the tile's first sample
-  int64_t fbs = (int64_t)(((ws + (uint64_t)p.goff) / (uint64_t)B) * (uint64_t)B) - (int64_t)p.goff;
-  int rbase = 0;
-  // per-thread constants of the filter transforms (a thread keeps its place t in its block for the whole kernel):
-  // its twiddles of both radix-8 passes, its 8 bins of the transformed taps; and the input window of the NEXT
-  // round, loaded a round ahead so that its HBM latency hides behind the transforms and the metric phase
-  const int gF = tid / TF, tF = tid % TF;
-  FftTwRegs<F> twr;
-  twr.load(p.twF, tF);
-  c32 Hr[8], xn[8];
-#pragma unroll
-  for (int m = 0; m < 8; m++) Hr[m] = p.Hf[tF + m * TF];
-  {
-    const int64_t x0 = fbs + (int64_t)gF * B - ntm1 + tF;
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int64_t xi = x0 + m * TF;
-      xn[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
-    }
-  }
+  int rbase = 0;  // the ring slot of the tile's first sample
+  // the next tile of y, fetched a tile ahead: its HBM latency hides behind the metric phase
+  float4 ypre[SYNC_V / 2];
+  bool have_pre = false;
   __syncthreads();
 
   for (uint64_t tile = tile_first; tile < tile_own1; tile++, rbase = (rbase + T >= R) ? rbase + T - R : rbase + T) {
@@ -483,83 +522,46 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     const bool owned = tile >= tile_own0;
     const bool masked = warm && (t0s < qvalid + D);  // some sample of the tile lacks real history
 
-    // ---- 1 + 2. channel filter: rounds of BPR overlap-save blocks until the tile is covered.  Ring hazards: a
-    //         round overwrites slots whose samples lie more than HY before this tile -- every read of them
-    //         happened before the last barrier of the previous iteration; the transforms' scratch overlays
-    //         mt / me / ue, which are dead by then for the same reason.
-    // issue priority: the metric phase below is a chain of short steps between workgroup barriers, each as slow as
-    // its slowest wave; the transforms are long, dense and barrier-free.  Waves in the metric phase go first, the
-    // co-resident workgroup's transforms fill the gaps (measured: -1 %).
-    __builtin_amdgcn_s_setprio(0);
-    while (fbs < t0s + T) {
-      const int g = tl / TF, t = tl % TF;
-      c32* sc = fsc + g * fft_lds_points(F);
-      const int64_t bs = fbs + (int64_t)g * B;  // first output sample of this thread's block
-      c32 e[8];
+    // ---- 1. the tile of y into the ring.  Ring hazards: the slots written hold samples more than HY before this
+    //         tile -- every read of them happened before the last barrier of the previous iteration.
+    if (have_pre) {
 #pragma unroll
-      for (int m = 0; m < 8; m++) e[m] = xn[m];
-      STAMP_VM(0);
-      fbs += (int64_t)BPR * B;
-      {
-        const int64_t x0 = fbs + (int64_t)g * B - ntm1 + t;
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-          const int64_t xi = x0 + m * TF;
-          xn[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
-        }
+      for (int r = 0; r < SYNC_V / 2; r++) {
+        const int li = sync_lp(ring_wrap(rbase + 2 * (tl + r * SYNC_THREADS), R));
+        ys[li] = mk(ypre[r].x, ypre[r].y);
+        ys[li + 1] = mk(ypre[r].z, ypre[r].w);
       }
-      if (!SYNC_ABLATE(p, 1)) {
-        if constexpr (TF <= WAVE) {
-          fft_run1<F, false>(e, t, sc, twr, FftWaveSync());
-        } else {
-          fft_run1<F, false>(e, t, sc, twr, FftBlockSync());
-        }
-        STAMP(11);
+    } else if (y_al16 && t0 + (uint64_t)T <= p.nsamples) {
+      const float4* src = reinterpret_cast<const float4*>(p.y + t0);
 #pragma unroll
-        for (int m = 0; m < 8; m++) e[m] = cmul(e[m], Hr[m]);  // volk_32fc_x2_multiply_32fc
-        STAMP(12);
-        if constexpr (TF <= WAVE) {
-          fft_run1<F, true>(e, t, sc, twr, FftWaveSync());
-        } else {
-          fft_run1<F, true>(e, t, sc, twr, FftBlockSync());
-        }
+      for (int r = 0; r < SYNC_V / 2; r++) {
+        const float4 v = src[tl + r * SYNC_THREADS];
+        const int li = sync_lp(ring_wrap(rbase + 2 * (tl + r * SYNC_THREADS), R));
+        ys[li] = mk(v.x, v.y);
+        ys[li + 1] = mk(v.z, v.w);
       }
-      STAMP(13);
-      const int rel0 = rbase + (int)(bs - t0s) - ntm1 + t;  // ring-relative position of transform point t
-      // (a capture's first block may start before its first sample: y before the stream stays zero)
-      const int first = ntm1 + ((bs < 0) ? (int)(-bs) : 0);
+    } else {
 #pragma unroll
-      for (int m = 0; m < 8; m++) {
-        if (t + m * TF >= first) ys[sync_lp(ring_wrap(rel0 + m * TF, R))] = e[m];
+      for (int r = 0; r < SYNC_V; r++) {
+        const int i = tl + r * SYNC_THREADS;
+        const uint64_t n = t0 + (uint64_t)i;
+        c32 v = mk(0.f, 0.f);
+        if (n < p.nsamples) v = p.y[n];
+        ys[sync_lp(ring_wrap(rbase + i, R))] = v;
       }
     }
+    have_pre = false;
+    if (tile + 1 < tile_own1 && y_al16 && t0 + 2ull * T <= p.nsamples) {
+      const float4* src = reinterpret_cast<const float4*>(p.y + t0 + T);
+#pragma unroll
+      for (int r = 0; r < SYNC_V / 2; r++) ypre[r] = src[tl + r * SYNC_THREADS];
+      have_pre = true;
+    }
     STAMP(1);
-    __builtin_amdgcn_s_setprio(2);
     __syncthreads();  // B2: the tile's y is in the ring
     STAMP(2);
     const int ybs = ring_wrap(rbase + SYNC_V * tl, R);
     const int yb = sync_lp(ybs), yb1 = sync_lp(ring_wrap(ybs - D, R)), yb2 = sync_lp(ring_wrap(ring_wrap(ybs - D, R) - D, R));
-
-    // ---- 3. y to HBM (owned tiles only), coalesced from the ring ----------------------------
-    if (owned && !SYNC_ABLATE(p, 4)) {
-      if (y_al16 && t0 + (uint64_t)T <= p.nsamples) {
-        float4* dst = reinterpret_cast<float4*>(p.y + t0);
-#pragma unroll
-        for (int r = 0; r < SYNC_V / 2; r++) {
-          const int pi = tl + r * SYNC_THREADS;
-          const int li = sync_lp(ring_wrap(rbase + 2 * pi, R));
-          const c32 a = ys[li], b = ys[li + 1];
-          dst[pi] = make_float4(a.re, a.im, b.re, b.im);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < SYNC_V; r++) {
-          const int i = tl + r * SYNC_THREADS;
-          const uint64_t n = t0 + (uint64_t)i;
-          if (n < p.nsamples) p.y[n] = ys[sync_lp(ring_wrap(rbase + i, R))];
-        }
-      }
-    }
 
     if (SYNC_ABLATE(p, 2)) {
       __syncthreads();
@@ -676,10 +678,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     // the CP newest M values become the next tile's history (every thread has done its reads of mh
     // and mt before B5; mt is free from here on)
     for (int i = tl; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = mt[sync_lp(T - HM + i)];
-    if (!owned) {  // warm-up tile: only the histories matter
-      __syncthreads();  // (the next tile's transforms overwrite mt, which the copy above reads)
-      continue;
-    }
+    if (!owned) continue;  // warm-up tile: only the histories matter
 
     float u[SYNC_V];
 #pragma unroll
@@ -722,7 +721,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     const int anyc = __syncthreads_or(amask != 0);  // B6
     STAMP(7);
     if (tl == 0 && !anyc) {
-      p.tile_B[tile] = (double)((scC[0] + scC[1]) + (scC[2] + scC[3]));
+      float tb = scC[0];
+      if (SYNC_THREADS / WAVE == 4) tb = (scC[0] + scC[1]) + (scC[2] + scC[3]);
+      else if (SYNC_THREADS / WAVE == 2) tb = scC[0] + scC[1];
+      p.tile_B[tile] = (double)tb;
       p.tile_npieces[tile] = 0;
     }
     if (!anyc) continue;  // (a tile with candidates gets its summary below, from the exact values)
