@@ -112,7 +112,7 @@ def cpu_baseline(cfg, sigma, lead, tail, size, npkt):
     same = eng.rx(iq) == pkts
     eng.close()
     del iq
-    # (b) one stream per core (ctypes releases the GIL inside the oracle), a quarter of the sample each
+    # (b) one stream per core (ctypes releases the GIL inside the oracle), half of the sample each
     cores = host_cores()
     per = max(256, npkt // 2)
     resn = {}
@@ -271,11 +271,11 @@ def main():
         kern = max(prof.items(), key=lambda kv: kv[1][0])
         kname, (kms, klaunch) = kern
         # algorithmic bytes of ONE launch of that kernel (DESIGN.md "Roofline accounting"):
-        #   k_sync / k_rx_demod : the compulsory read of the received stream, (N+CP)*8 B per symbol
+        #   k_chan_filter / k_sync / k_rx_demod : the compulsory read of the received stream, (N+CP)*8 B per symbol
         #   k_tx_mod            : the compulsory write of the stream + the packet bits in
         nbits = int(np.ceil(np.log2(cfg.arity)))
         bits_b = ncar * nbits / 8.0                                    # payload bits of one symbol, in bytes
-        per_symbol = {"k_sync": L * 8.0, "k_rx_demod": N * 8.0 + bits_b,
+        per_symbol = {"k_sync": L * 8.0, "k_chan_filter": L * 8.0, "k_rx_demod": N * 8.0 + bits_b,
                       "k_tx_mod": L * 8.0 + bits_b}.get(kname, L * 8.0)
         launch_bytes = per_symbol * nsym
         avg_s = (kms / max(klaunch, 1)) * 1e-3
@@ -283,15 +283,20 @@ def main():
         path_bytes = 2 * L * 8.0 + 2 * bits_b                        # 10 339 B per symbol at C2
         # HBM traffic of that kernel from the committed PMC passes of this same command (cannot be collected from
         # inside the process): read + write bytes per symbol x symbols of one launch; null for other configs
+        # (tools/make_pmc_traffic.py stamps the file with a hash of the kernel sources: a stale file is not quoted)
         traffic, traffic_src = None, None
         try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from make_pmc_traffic import sources_sha
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)) as f:
                 pmc = json.load(f)
             bps = pmc["bytes_per_symbol"].get(kname)
-            if bps:
+            if pmc.get("sources_sha") != sources_sha():
+                traffic_src = "stale: %s was collected on other kernel sources" % pmc.get("source")
+            elif bps:
                 traffic = (bps["read"] + bps["write"]) * nsym
                 traffic_src = pmc["source"]
-        except (IOError, OSError, ValueError, KeyError):
+        except (ImportError, IOError, OSError, ValueError, KeyError):
             pass
         out = {
             "metric": "OFDM symbols/sec (TX+loopback RX) @ N_fft=512; packet CRC pass rate",

@@ -83,9 +83,11 @@ class ofdm_mod(object):
         if isinstance(payload, str):
             payload = payload.encode("latin-1")
         payload = bytes(payload)
-        # same limit and exception as make_packet (ofdm_packet_utils.py:123-126)
+        # same limit and exception as make_packet (ofdm_packet_utils.py:123-126) -- and, like it, raised HERE for
+        # the offending packet only: the padded, whitened body must fit the mask too (whiten(), :84-87)
         if len(payload) + 4 > len(ofdm_packet_utils.random_mask_tuple):
             raise ValueError("len(payload) must be in [0, %d]" % (len(ofdm_packet_utils.random_mask_tuple),))
+        self._engine.framed_len(len(payload))        # ValueError when the whitening mask is exhausted
         self._pending.append(payload)
 
     def reset_carrier_map(self, carrier_map_new):
@@ -99,12 +101,12 @@ class ofdm_mod(object):
         """Modulate everything queued so far; returns the samples (also written to the sink)."""
         if not self._pending:
             return None
-        iq = self._engine.tx(self._pending)
+        pending, self._pending = self._pending, []   # a failing batch never poisons the queue
+        iq = self._engine.tx(pending)
         self.symbols_sent += self._engine.last_stats.get("symbols", 0)
-        self.packets_sent += len(self._pending)
+        self.packets_sent += len(pending)
         if self._log:
             self._write_logs(iq)
-        self._pending = []
         if self._sink is not None:
             self._sink.write(iq)
         return iq
