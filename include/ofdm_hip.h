@@ -97,7 +97,17 @@ typedef struct ofdm_cfg {
    * (transmit_path.py:64).  Used identically by the mapper (container fft_length) and the
    * frame sink (container occupied_tones); see ofdm_set_carrier_map. */
   char carrier_map[OFDM_MAX_CARRIER_HEX + 8];
+
+  /* ofdm_receiver's SYNC selector (ofdm_receiver.py~:89-119).  OFDM_SYNC_PN is the reference's hard-wired choice;
+   * OFDM_SYNC_FIXED is its "for testing only" branch (:108-119): chan_filt = multiply_const(1.0), a timing flag on
+   * the last sample of every fixed_nsymbols-th symbol starting with the first (ofdm_sync_fixed), a constant
+   * frequency-offset input to the NCO.  ("ml" and "pnac" need blocks the reference's tree does not hold.) */
+  uint32_t sync_mode;
+  uint32_t fixed_nsymbols;   /* symbols per packet incl. the preamble (reference: 18) */
+  float fixed_freq_offset;   /* reference: 0.0 */
+  uint32_t reserved0;
 } ofdm_cfg;
+enum { OFDM_SYNC_PN = 0, OFDM_SYNC_FIXED = 1 };
 
 /* Synthetic channel fused into the TX store (replaces the UHD sink/source pair
  * usrp_transmit_path.py:66-72 / usrp_receive_path.py:67-73 for loopback). */
@@ -290,8 +300,16 @@ enum {
   OFDM_TAP_RX_ACQ = 8,       /* c32[nsym][occ]: ofdm_receiver-frame_acq_c.dat                     */
   OFDM_TAP_RX_SINK = 9,      /* c32[ndemapped][occ]: ofdm_frame_sink_c.dat (derotated carriers)   */
   OFDM_TAP_RX_PACKETS = 10,  /* uint8: frame-sink messages before dewhitening, concatenated      */
-  OFDM_TAP_COUNT = 11
+  OFDM_TAP_TX_MAPPER = 11,   /* c32[ndata][N]: ofdm_mapper_c.dat (mapper output: data symbols only, ofdm.py:124) */
+  OFDM_TAP_TX_IFFT = 12,     /* c32[nsym][N]: ofdm_ifft_c.dat (transform output before the cyclic prefix, ofdm.py:128) */
+  OFDM_TAP_RX_SAMPLER = 13,  /* c32[nsym][N]: ofdm_receiver-sampler_c.dat (the sampled, derotated symbols = FFT input) */
+  OFDM_TAP_RX_SIGMIX = 14,   /* c32[nsamples]: ofdm_receiver-sigmix_c.dat (chan_filt * nco, whole stream)  */
+  OFDM_TAP_RX_NCO = 15,      /* c32[nsamples]: ofdm_receiver-nco_c.dat (frequency_modulator_fc output)     */
+  OFDM_TAP_COUNT = 16
 };
+/* SIGMIX / NCO evaluate the NCO's closed form sample by sample over the whole stream; inside the symbols the
+ * sampler picks, the receiver itself advances the same phasor by a float64 recurrence: RX_SAMPLER is
+ * bit for bit what the FFT consumed, RX_SIGMIX may differ from it in the last float32 bit. */
 int ofdm_set_taps(ofdm_handle *h, uint32_t tap_mask); /* bit i enables OFDM_TAP_i */
 int ofdm_tap(ofdm_handle *h, int tap, void *out_host, uint64_t cap_bytes, uint64_t *nbytes);
 

@@ -26,7 +26,9 @@ OFDM_F_DEVICE_PTRS = 1 << 0
 OFDM_F_PAD_FOR_USRP = 1 << 1
 
 (TAP_TX_PACKETS, TAP_TX_FREQ, TAP_RX_CHAN_FILT, TAP_RX_METRIC, TAP_RX_PEAKS, TAP_RX_ANGLES,
- TAP_RX_FRAMES, TAP_RX_FFT, TAP_RX_ACQ, TAP_RX_SINK, TAP_RX_PACKETS, TAP_COUNT) = range(12)
+ TAP_RX_FRAMES, TAP_RX_FFT, TAP_RX_ACQ, TAP_RX_SINK, TAP_RX_PACKETS, TAP_TX_MAPPER, TAP_TX_IFFT, TAP_RX_SAMPLER,
+ TAP_RX_SIGMIX, TAP_RX_NCO, TAP_COUNT) = range(17)
+SYNC_PN, SYNC_FIXED = 0, 1
 
 (K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_COUNT) = range(10)
 OFDM_SENSE_MAX_FFT = 4096
@@ -62,6 +64,10 @@ class ofdm_cfg(C.Structure):
         ("whitener_offset", C.c_uint32),
         ("pad_seed", C.c_uint64),
         ("carrier_map", C.c_char * (OFDM_MAX_CARRIER_HEX + 8)),
+        ("sync_mode", C.c_uint32),
+        ("fixed_nsymbols", C.c_uint32),
+        ("fixed_freq_offset", C.c_float),
+        ("reserved0", C.c_uint32),
     ]
 
 

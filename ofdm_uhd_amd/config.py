@@ -174,6 +174,16 @@ def make_cfg(options, pad_for_usrp=False, device_ptrs=False, device_id=0, pad_se
     cfg.pad_seed = int(pad_seed)
     if carriers is None:
         carriers = getattr(options, "carrier_map", None)
+    # ofdm_receiver's SYNC selector (ofdm_receiver.py~:89): "pn" is the reference's hard-wired choice, "fixed" its
+    # for-testing-only branch (:108-119: nsymbols = 18, freq_offset = 0.0); "ml" / "pnac" need blocks its tree lacks
+    sync = getattr(options, "sync", "pn") or "pn"
+    if sync not in ("pn", "fixed"):
+        raise ValueError("SYNC must be 'pn' or 'fixed' (ofdm_sync_ml / ofdm_sync_pnac are not part of the reference's tree)")
+    cfg.sync_mode = _abi.SYNC_FIXED if sync == "fixed" else _abi.SYNC_PN
+    cfg.fixed_nsymbols = int(getattr(options, "sync_nsymbols", 18))
+    cfg.fixed_freq_offset = float(getattr(options, "sync_freq_offset", 0.0))
+    if cfg.sync_mode == _abi.SYNC_FIXED and cfg.fixed_nsymbols < 1:
+        raise ValueError("sync_nsymbols must be >= 1")
     if carriers and len(carriers) > _abi.OFDM_MAX_CARRIER_HEX:
         raise ValueError("carrier map longer than %d hex digits" % _abi.OFDM_MAX_CARRIER_HEX)
     # raises ValueError exactly where the blocks' constructors would throw -- or would index outside their

@@ -62,7 +62,8 @@ struct ofdm_handle {
 
   // TX workspaces
   DevBuf d_payloads, d_payload_off, d_payload_len, d_framed, d_framed_off, d_sym_off, d_sym_pkt, d_iq_stage,
-      d_freq_tap;
+      d_freq_tap, d_ifft_tap;
+  std::vector<uint64_t> last_sym_off;  // symbol offsets of the last transmitted batch (TX_MAPPER tap)
   PinBuf h_meta;
   std::vector<uint64_t> framed_off, sym_off;
   uint64_t last_tx_nsym = 0, last_tx_framed_bytes = 0;
@@ -255,6 +256,9 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   if (!(cfg->peak_rise > 0.f) || !(cfg->peak_fall > 0.f) || !(cfg->peak_alpha > 0.f) || !(cfg->peak_alpha < 1.f))
     FAIL(h, OFDM_E_INVAL, "peak detector factors must be positive, alpha in (0,1)");
   if (cfg->max_fft_shift_len > 64) FAIL(h, OFDM_E_INVAL, "max_fft_shift_len too large");
+  if (cfg->sync_mode != OFDM_SYNC_PN && cfg->sync_mode != OFDM_SYNC_FIXED)
+    FAIL(h, OFDM_E_INVAL, "sync_mode must be OFDM_SYNC_PN or OFDM_SYNC_FIXED (\"ml\" / \"pnac\" need blocks the reference does not ship)");
+  if (cfg->sync_mode == OFDM_SYNC_FIXED && cfg->fixed_nsymbols < 1) FAIL(h, OFDM_E_INVAL, "fixed_nsymbols must be >= 1");
   h->N = N;
   h->CP = CP;
   h->L = N + CP;
@@ -376,7 +380,7 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
   DevBuf* bufs[] = {&h->d_const,    &h->d_preamble,    &h->d_tw,          &h->d_bin2car, &h->d_mask,
                     &h->d_crc,      &h->d_Hf,   &h->d_twF,     &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
                     &h->d_payloads, &h->d_payload_off, &h->d_payload_len, &h->d_framed,  &h->d_framed_off,
-                    &h->d_sym_off,  &h->d_sym_pkt,     &h->d_iq_stage,    &h->d_freq_tap};
+                    &h->d_sym_off,  &h->d_sym_pkt,     &h->d_iq_stage,    &h->d_freq_tap, &h->d_ifft_tap};
   for (DevBuf* b : bufs) b->release();
   h->h_meta.release();
   h->rx.release();
@@ -577,13 +581,13 @@ extern "C" int ofdm_make_packets(ofdm_handle* h, const uint8_t* payloads, const 
 
 template <int N>
 static void launch_tx_mod(ofdm_handle* h, const TxParams& p, const uint8_t* d_framed, uint32_t uniform_spp, uint64_t nsym,
-                          uint64_t lead, c32* d_out, c32* d_freq_tap) {
+                          uint64_t lead, c32* d_out, c32* d_freq_tap, c32* d_ifft_tap) {
   constexpr int SPW = TxGeom<N>::SPW, WG = TxGeom<N>::WG;
   const size_t shmem = (size_t)SPW * fft_lds_bytes(N);
   const unsigned grid = (unsigned)((nsym + SPW - 1) / SPW);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N>), dim3(grid), dim3(WG), shmem, h->stream, p, d_framed,
                      h->d_framed_off.as<uint64_t>(), h->d_sym_off.as<uint64_t>(), h->d_sym_pkt.as<uint32_t>(),
-                     uniform_spp, nsym, lead, d_out, d_freq_tap);
+                     uniform_spp, nsym, lead, d_out, d_freq_tap, d_ifft_tap);
 }
 
 static int launch_noise(ofdm_handle* h, c32* d_iq, uint64_t n, uint64_t index0, int zero_input, const ofdm_chan& ch) {
@@ -639,27 +643,32 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
                          h->d_sym_pkt.as<uint32_t>());
       HIPCHK(h, hipGetLastError());
     }
-    c32* d_freq = nullptr;
-    if (h->tap_mask & (1u << OFDM_TAP_TX_FREQ)) {
+    c32 *d_freq = nullptr, *d_ifft = nullptr;
+    if (h->tap_mask & ((1u << OFDM_TAP_TX_FREQ) | (1u << OFDM_TAP_TX_MAPPER))) {
       HIPCHK(h, h->d_freq_tap.ensure(nsym * (uint64_t)h->N * sizeof(c32)));
       d_freq = h->d_freq_tap.as<c32>();
+    }
+    if (h->tap_mask & (1u << OFDM_TAP_TX_IFFT)) {
+      HIPCHK(h, h->d_ifft_tap.ensure(nsym * (uint64_t)h->N * sizeof(c32)));
+      d_ifft = h->d_ifft_tap.as<c32>();
     }
     TxParams p = make_tx_params(h);
     const uint32_t uspp = uni ? spp : 0;
     h->prof.begin(OFDM_K_TX, h->stream);
     switch (h->N) {
-      case 64: launch_tx_mod<64>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
-      case 128: launch_tx_mod<128>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
-      case 256: launch_tx_mod<256>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
-      case 512: launch_tx_mod<512>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
-      case 1024: launch_tx_mod<1024>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
-      case 2048: launch_tx_mod<2048>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
-      default: launch_tx_mod<4096>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq); break;
+      case 64: launch_tx_mod<64>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
+      case 128: launch_tx_mod<128>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
+      case 256: launch_tx_mod<256>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
+      case 512: launch_tx_mod<512>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
+      case 1024: launch_tx_mod<1024>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
+      case 2048: launch_tx_mod<2048>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
+      default: launch_tx_mod<4096>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
     }
     h->prof.end(h->stream);
     HIPCHK(h, hipGetLastError());
   }
   h->last_tx_nsym = nsym;
+  h->last_sym_off = h->sym_off;
   h->last_tx_npkt = npkt;
   h->last_tx_framed_bytes = npkt ? h->framed_off[npkt] : 0;
   // noise-only lead-in and tail (the modulator covers everything in between)

@@ -48,6 +48,9 @@ struct FramesParams {
   // carry their known phase step instead of one derived from this call's correlator output
   uint64_t nforced;
   const double* forced_step;
+  // SYNC "fixed": the NCO's frequency input is a constant, not complex_to_arg(P) at the flag
+  int fixed_on;
+  float fixed_angle;
 };
 
 // NCO phase bookkeeping across flags is done in integers: a phase advance x (radians) becomes
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(256) k_frames(FramesParams q) {
   if (j >= q.npeaks) return;
   const uint64_t p = q.peaks[j];
   const c32 P = q.peak_P[j];
-  const float ang = det_atan2f(P.im, P.re);  // complex_to_arg, bit-reproducible form
+  const float ang = q.fixed_on ? q.fixed_angle : det_atan2f(P.im, P.re);  // complex_to_arg, bit-reproducible form
   q.angle[j] = ang;
   double st = (double)(q.sens * ang);
   if (j < q.nforced) st = q.forced_step[j];
@@ -142,6 +145,7 @@ struct DemodParams {
   const uint8_t* invalid;  // [nframes] (tap pass)
   FrameResult* res;        // [nframes]
   uint8_t* raw;            // [nframes][RAW_SLOT]
+  c32* tap_sampler;        // optional [nsym][N]: the FFT's input
   c32* tap_fft;            // optional [nsym][N]
   c32* tap_acq;            // optional [nsym][occ]
   c32* tap_sink;           // optional [nsym][occ]
@@ -367,6 +371,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
           const dc r = dexpj(ph);
           e[m] = cmul(e[m], mk((float)r.re, (float)r.im));
         }
+      }
+      if (q.tap_sampler) {  // ofdm_receiver-sampler_c.dat: the sampled, derotated symbol
+#pragma unroll
+        for (int m = 0; m < 8; m++) q.tap_sampler[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = e[m];
       }
       // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
       fft_run<N, false>(e, tl, fftbuf, q.tw, [] { __syncthreads(); });
@@ -789,14 +797,39 @@ __global__ void __launch_bounds__(256) k_nco_phase(const uint64_t* __restrict__ 
   Phi[i] = nco_radians(u);
 }
 
+// ofdm_receiver-sigmix_c.dat / -nco_c.dat (ofdm_receiver.py~:150-152): the NCO's closed form sample by sample over
+// the whole stream, phi[n] = Phi_j + step_j (n - p_j + 1) for p_j <= n < p_{j+1} (0 before the first flag, or the
+// line carried in / the constant of SYNC "fixed"), nco = expj(phi) rounded to float32, sigmix = chan_filt * nco.
+__global__ void __launch_bounds__(256) k_sigmix_tap(const c32* __restrict__ y, uint64_t n, const uint64_t* __restrict__ peaks,
+                                                     const double* __restrict__ Phi, const double* __restrict__ step,
+                                                     uint64_t npeaks, int ref_on, int64_t ref_peak, double ref_phi,
+                                                     double ref_step, c32* __restrict__ sigmix, c32* __restrict__ nco) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t lo = 0, hi = npeaks;  // first flag > i
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (peaks[mid] <= i) lo = mid + 1;
+    else hi = mid;
+  }
+  double ph = 0.0;
+  if (lo > 0) ph = Phi[lo - 1] + step[lo - 1] * (double)(i - peaks[lo - 1] + 1);
+  else if (ref_on) ph = ref_phi + ref_step * (double)((int64_t)i - ref_peak + 1);
+  const dc r = dexpj(ph);
+  const c32 rot = mk((float)r.re, (float)r.im);
+  if (nco) nco[i] = rot;
+  if (sigmix) sigmix[i] = cmul(y[i], rot);
+}
+
 // ------------------------------------------------------------------------------------
 // receive-side workspaces
 // ------------------------------------------------------------------------------------
 struct RxState {
   DevBuf x_stage, y, metric, tile_B, tile_np, tile_first, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
       partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
-      out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, stash_peaks, stash_P, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos;
+      out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, stash_peaks, stash_P, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos, tap_sampler, tap_sigmix, tap_nco;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
+  const c32* y_ptr = nullptr;  // chan_filt's output of the last call: rx.y, or the input itself (SYNC "fixed")
   uint64_t origin = 0;  // index, in its capture, of the first sample of the ofdm_rx calls (ofdm_rx_set_origin)
   std::vector<uint64_t> last_pos;  // host copy: flag sample of every packet of the last call
   // chunked streams (ofdm_rx_set_flag_history): flags settled by earlier calls replace whatever this call
@@ -814,7 +847,7 @@ struct RxState {
                      &cand_P,  &counters, &counts, &offsets,  &partial,  &peaks,       &peak_P,     &angle,
                      &step,    &inc,    &Phi,     &K,        &nsym,     &sym_base,    &res,        &raw,
                      &invalid, &chain_list, &key, &pos,      &out_payload, &out_off,  &out_len,    &out_ok,
-                     &out_pos, &inc_acc, &Phi_u, &peaks2, &peak_P2, &fstep, &pre_inv, &stash_peaks, &stash_P, &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos};
+                     &out_pos, &inc_acc, &Phi_u, &peaks2, &peak_P2, &fstep, &pre_inv, &stash_peaks, &stash_P, &tap_fft, &tap_acq, &tap_sink, &tap_demapped, &raw_tap, &raw_lens, &raw_pos, &tap_sampler, &tap_sigmix, &tap_nco};
     for (DevBuf* b : all) b->release();
   }
 };

@@ -210,7 +210,8 @@ template <int N>
 __global__ void __launch_bounds__(TxGeom<N>::WG)
     k_tx_mod(TxParams p, const uint8_t* __restrict__ framed, const uint64_t* __restrict__ framed_off,
              const uint64_t* __restrict__ sym_off, const uint32_t* __restrict__ sym_pkt, uint32_t uniform_spp,
-             uint64_t nsym, uint64_t lead, c32* __restrict__ out, c32* __restrict__ freq_tap) {
+             uint64_t nsym, uint64_t lead, c32* __restrict__ out, c32* __restrict__ freq_tap,
+             c32* __restrict__ ifft_tap) {
   constexpr int T = TxGeom<N>::T, SPW = TxGeom<N>::SPW;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   c32* lds = reinterpret_cast<c32*>(smem_raw) + (threadIdx.x / T) * (fft_lds_bufs(N) * fft_lds_points(N));
@@ -282,6 +283,10 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
   }
 
   if (!active) return;
+  if (ifft_tap) {  // ofdm_ifft_c.dat (ofdm.py:128): the transform's output vectors, before the cyclic prefix
+#pragma unroll
+    for (int m = 0; m < 8; m++) ifft_tap[sym * N + (uint64_t)(t + m * T)] = e[m];
+  }
   const uint64_t base = lead + sym * (uint64_t)p.L;
   c32* o = out + base;
   c32 v[8];

@@ -358,7 +358,9 @@ class Engine(object):
         _abi.TAP_TX_PACKETS: np.uint8, _abi.TAP_TX_FREQ: np.complex64, _abi.TAP_RX_CHAN_FILT: np.complex64,
         _abi.TAP_RX_METRIC: np.float32, _abi.TAP_RX_PEAKS: np.uint64, _abi.TAP_RX_ANGLES: np.float32,
         _abi.TAP_RX_FRAMES: np.uint64, _abi.TAP_RX_FFT: np.complex64, _abi.TAP_RX_ACQ: np.complex64,
-        _abi.TAP_RX_SINK: np.complex64, _abi.TAP_RX_PACKETS: np.uint8,
+        _abi.TAP_RX_SINK: np.complex64, _abi.TAP_RX_PACKETS: np.uint8, _abi.TAP_TX_MAPPER: np.complex64,
+        _abi.TAP_TX_IFFT: np.complex64, _abi.TAP_RX_SAMPLER: np.complex64, _abi.TAP_RX_SIGMIX: np.complex64,
+        _abi.TAP_RX_NCO: np.complex64,
     }
 
     def tap(self, tap):
@@ -370,7 +372,7 @@ class Engine(object):
             self._check(self._lib.ofdm_tap(self._h, tap, _ptr(out), nb.value, C.byref(nb)))
         if tap == _abi.TAP_RX_FRAMES:
             out = out.reshape(-1, 2)
-        elif tap in (_abi.TAP_TX_FREQ, _abi.TAP_RX_FFT):
+        elif tap in (_abi.TAP_TX_FREQ, _abi.TAP_RX_FFT, _abi.TAP_TX_MAPPER, _abi.TAP_TX_IFFT, _abi.TAP_RX_SAMPLER):
             out = out.reshape(-1, self.N)
         elif tap in (_abi.TAP_RX_ACQ, _abi.TAP_RX_SINK):
             out = out.reshape(-1, self.occ)

@@ -57,7 +57,7 @@ class ofdm_mod(object):
         if getattr(options, "verbose", False):
             self._print_verbage()
         if getattr(options, "log", False):
-            self._engine.set_taps(engine._abi.TAP_TX_FREQ)
+            self._engine.set_taps(engine._abi.TAP_TX_FREQ, engine._abi.TAP_TX_MAPPER, engine._abi.TAP_TX_IFFT)
         self._log = bool(getattr(options, "log", False))
 
     # -- wiring -------------------------------------------------------------------
@@ -113,9 +113,14 @@ class ofdm_mod(object):
 
     def _write_logs(self, iq):
         # the reference's --log probe points (ofdm.py:123-131)
-        freq = self._engine.tap(engine._abi.TAP_TX_FREQ)
-        iqio.file_sink("ofdm_preambles.dat", append=True).write(freq.reshape(-1))
-        iqio.file_sink("ofdm_cp_adder_c.dat", append=True).write(iq)
+        A = engine._abi
+        iqio.file_sink("ofdm_mapper_c.dat", append=True).write(self._engine.tap(A.TAP_TX_MAPPER).reshape(-1))
+        iqio.file_sink("ofdm_preambles.dat", append=True).write(self._engine.tap(A.TAP_TX_FREQ).reshape(-1))
+        ifft = self._engine.tap(A.TAP_TX_IFFT)
+        iqio.file_sink("ofdm_ifft_c.dat", append=True).write(ifft.reshape(-1))
+        # ofdm_cp_adder_c.dat: cp_adder's output, BEFORE the 1/sqrt(N) scale block (ofdm.py:113-114,130)
+        cp = self._cp_length
+        iqio.file_sink("ofdm_cp_adder_c.dat", append=True).write(np.concatenate([ifft[:, ifft.shape[1] - cp:], ifft], axis=1).reshape(-1))
 
     def add_options(normal, expert):
         """
@@ -171,7 +176,8 @@ class ofdm_demod(object):
         self._engine = engine.Engine(options, device_id=device_id)
         self._log = bool(getattr(options, "log", False))
         if self._log:
-            self._engine.set_taps(engine._abi.TAP_RX_FFT, engine._abi.TAP_RX_ACQ, engine._abi.TAP_RX_SINK)
+            self._engine.set_taps(engine._abi.TAP_RX_FFT, engine._abi.TAP_RX_ACQ, engine._abi.TAP_RX_SINK,
+                                  engine._abi.TAP_RX_SAMPLER, engine._abi.TAP_RX_SIGMIX, engine._abi.TAP_RX_NCO)
         self.n_packets = 0
         self.n_ok = 0
         self._streaming = False      # feed() has data or history pending
@@ -240,6 +246,8 @@ class ofdm_demod(object):
     def feed(self, iq, flush=False):
         """Demodulate the next chunk of a continuous capture; returns the packets that became final.
         ``flush=True`` (or flush()) ends the stream: everything still held back is delivered."""
+        if self._engine.cfg.sync_mode != engine._abi.SYNC_PN:
+            raise ValueError("feed() needs SYNC 'pn': ofdm_sync_fixed's flags are positions in the whole capture")
         self._streaming = True
         T, span, lookback = self._stream_geometry()
         iq = np.ascontiguousarray(iq, np.complex64)
@@ -307,6 +315,9 @@ class ofdm_demod(object):
         iqio.file_sink("ofdm_receiver-chan_filt_c.dat").write(e.tap(A.TAP_RX_CHAN_FILT))
         iqio.file_sink("ofdm_receiver-fft_out_c.dat").write(e.tap(A.TAP_RX_FFT).reshape(-1))
         iqio.file_sink("ofdm_receiver-frame_acq_c.dat").write(e.tap(A.TAP_RX_ACQ).reshape(-1))
+        iqio.file_sink("ofdm_receiver-sampler_c.dat").write(e.tap(A.TAP_RX_SAMPLER).reshape(-1))
+        iqio.file_sink("ofdm_receiver-sigmix_c.dat").write(e.tap(A.TAP_RX_SIGMIX))
+        iqio.file_sink("ofdm_receiver-nco_c.dat").write(e.tap(A.TAP_RX_NCO))
         iqio.file_sink("ofdm_frame_sink_c.dat").write(e.tap(A.TAP_RX_SINK).reshape(-1))
 
     def add_options(normal, expert):

@@ -610,6 +610,13 @@ static int msg_chunk(const uint8_t *msg, uint32_t len, uint64_t c, int nbits) {
 int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload_off,
            const uint32_t *payload_len, int npkt, uint64_t lead, ofdm_c32 *iq_out, uint64_t iq_cap,
            uint64_t *nsamples_out, ofdm_c32 *freq_tap, uint8_t *framed_tap, uint64_t *framed_off_tap) {
+  return orc_tx_ex(cfg, payloads, payload_off, payload_len, npkt, lead, iq_out, iq_cap, nsamples_out, freq_tap, framed_tap,
+                   framed_off_tap, NULL);
+}
+/* ifft_tap: [nsym][N], the transform's output vectors before the cyclic prefix (ofdm_ifft_c.dat, ofdm.py:128) */
+int orc_tx_ex(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload_off,
+              const uint32_t *payload_len, int npkt, uint64_t lead, ofdm_c32 *iq_out, uint64_t iq_cap,
+              uint64_t *nsamples_out, ofdm_c32 *freq_tap, uint8_t *framed_tap, uint64_t *framed_off_tap, ofdm_c32 *ifft_tap) {
   int N = (int)cfg->fft_length, CP = (int)cfg->cp_length, occ = (int)cfg->occupied_tones;
   int L = N + CP;
   int nbits = orc_nbits(cfg);
@@ -662,6 +669,7 @@ int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload
       /* gr.fft_vcc(N, False, [], True): swap input halves, unnormalised inverse DFT (ofdm.py:112) */
       for (int k = 0; k < N; k++) tmp[k] = sym[(k + N / 2) % N];
       fft_exec(&plan, tmp, 1);
+      if (ifft_tap) memcpy(ifft_tap + nsym_total * (uint64_t)N, tmp, sizeof(ofdm_c32) * (size_t)N);
       if (pos + (uint64_t)L > iq_cap) {
         rc = OFDM_E_CAPACITY;
         break;
@@ -756,6 +764,9 @@ struct orc_rx_result {
   vec fft;      /* c32 */
   vec acq;      /* c32 */
   vec sink;     /* c32 */
+  vec sampler;  /* c32: the sampled, derotated symbols (FFT input) */
+  vec sigmix;   /* c32 [nsamples] */
+  vec nco;      /* c32 [nsamples] */
   vec raw;      /* u8: frame sink messages, concatenated */
   vec raw_off;  /* u64 */
   vec payload;  /* u8 */
@@ -1051,6 +1062,9 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   vec_init(&r->fft, sizeof(ofdm_c32));
   vec_init(&r->acq, sizeof(ofdm_c32));
   vec_init(&r->sink, sizeof(ofdm_c32));
+  vec_init(&r->sampler, sizeof(ofdm_c32));
+  vec_init(&r->sigmix, sizeof(ofdm_c32));
+  vec_init(&r->nco, sizeof(ofdm_c32));
   vec_init(&r->raw, 1);
   vec_init(&r->raw_off, sizeof(uint64_t));
   vec_init(&r->payload, 1);
@@ -1064,15 +1078,24 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
     return r;
   }
 
-  /* --- chan_filt ------------------------------------------------------- */
+  int fixed = cfg->sync_mode == OFDM_SYNC_FIXED;
   ofdm_c32 *y = (ofdm_c32 *)vec_push(&r->y, n);
-  chan_filter(cfg, iq, n, y);
-
-  /* --- ofdm_sync_pn ---------------------------------------------------- */
-  float *u = (float *)vec_push(&r->metric, n);
-  ofdm_c32 *P = (ofdm_c32 *)malloc(sizeof(ofdm_c32) * n);
-  sync_metric(cfg, y, n, u, P);
-  peak_detect(cfg, u, n, &r->peaks);
+  ofdm_c32 *P = (ofdm_c32 *)calloc(n, sizeof(ofdm_c32));
+  if (!fixed) {
+    /* --- chan_filt ------------------------------------------------------- */
+    chan_filter(cfg, iq, n, y);
+    /* --- ofdm_sync_pn ---------------------------------------------------- */
+    float *u = (float *)vec_push(&r->metric, n);
+    sync_metric(cfg, y, n, u, P);
+    peak_detect(cfg, u, n, &r->peaks);
+  } else {
+    /* SYNC = "fixed" (ofdm_receiver.py~:108-119, "for testing only"): chan_filt = gr.multiply_const_cc(1.0);
+     * ofdm_sync_fixed: a vector source repeating nsymbols*(N+CP) bytes with a 1 at index (N+CP)-1, and a constant
+     * frequency-offset stream into the NCO. */
+    memcpy(y, iq, sizeof(ofdm_c32) * n);
+    uint64_t period = (uint64_t)cfg->fixed_nsymbols * (uint64_t)L;
+    for (uint64_t p0 = (uint64_t)L - 1; p0 < n; p0 += period) *(uint64_t *)vec_push(&r->peaks, 1) = p0;
+  }
   uint64_t npk = r->peaks.n;
   const uint64_t *pk = (const uint64_t *)r->peaks.p;
   r->st.peaks = npk;
@@ -1088,8 +1111,17 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   /* The phase a flag starts from is kept modulo one turn as an integer (unit 2^-64 turn): integer addition is
    * associative, so the engine's parallel scan over the flags gives the same bits as this running sum. */
   uint64_t phi_u = 0;
+  /* the NCO line before the first flag: phase 0 -- except SYNC "fixed", whose constant frequency input drives the
+   * NCO from the first sample: phi[n] = ref_step * (n + 1) */
+  int ref_on = fixed && cfg->fixed_freq_offset != 0.0f;
+  double ref_step = (double)(sens * cfg->fixed_freq_offset);
+  if (ref_on && npk > 0) {
+    double t = ref_step * (double)pk[0] * 0.15915494309189533577;
+    t -= floor(t);
+    phi_u = (uint64_t)(t * 18446744073709551616.0);
+  }
   for (uint64_t j = 0; j < npk; j++) {
-    ang[j] = orc_atan2f(P[pk[j]].im, P[pk[j]].re);
+    ang[j] = fixed ? cfg->fixed_freq_offset : orc_atan2f(P[pk[j]].im, P[pk[j]].re);
     step[j] = (double)(sens * ang[j]);
     Phi[j] = (double)(int64_t)phi_u * 3.4061215800865545e-19; /* 2 pi / 2^64: phase in [-pi, pi) */
     if (j + 1 < npk) {
@@ -1099,6 +1131,22 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
     }
   }
   free(P);
+  /* ofdm_receiver-sigmix_c.dat / -nco_c.dat: the closed form sample by sample over the whole stream */
+  if (tap_mask & ((1u << OFDM_TAP_RX_SIGMIX) | (1u << OFDM_TAP_RX_NCO))) {
+    ofdm_c32 *sm = (tap_mask & (1u << OFDM_TAP_RX_SIGMIX)) ? (ofdm_c32 *)vec_push(&r->sigmix, n) : NULL;
+    ofdm_c32 *nc = (tap_mask & (1u << OFDM_TAP_RX_NCO)) ? (ofdm_c32 *)vec_push(&r->nco, n) : NULL;
+    uint64_t cnt = 0;
+    for (uint64_t i = 0; i < n; i++) {
+      while (cnt < npk && pk[cnt] <= i) cnt++;
+      double ph = 0.0;
+      if (cnt > 0) ph = Phi[cnt - 1] + step[cnt - 1] * (double)(i - pk[cnt - 1] + 1);
+      else if (ref_on) ph = 0.0 + ref_step * (double)((int64_t)i - 0 + 1);
+      dcx rr = orc_expj(ph);
+      ofdm_c32 rot = c32((float)rr.re, (float)rr.im);
+      if (nc) nc[i] = rot;
+      if (sm) sm[i] = cmul(y[i], rot);
+    }
+  }
 
   /* --- per-symbol machinery -------------------------------------------- */
   int zl = (N - occ + 1) / 2;
@@ -1206,9 +1254,11 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
             RTp = orc_expj(stq * (double)T);
           }
           dcx Rflag = orc_expj(Phi[j] + st);
+          if (j == 0 && ref_on) RTp = orc_expj(ref_step * (double)T);
           for (int t = 0; t < T; t++) {
             dcx rr = {1.0, 0.0};
             if (j > 0) rr = orc_expj(Phi[j - 1] + stq * (double)((int64_t)(sym_start + (uint64_t)t) - (int64_t)pk[j - 1] + 1));
+            else if (ref_on) rr = orc_expj(0.0 + ref_step * (double)((int64_t)(sym_start + (uint64_t)t) - 0 + 1));
             for (int m = 0; m < 8; m++) {
               int i = t + m * T;
               ofdm_c32 rot = c32((float)rr.re, (float)rr.im);
@@ -1224,6 +1274,7 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
             while (q >= 0 && pk[q] > idx) q--;
             double ph = 0.0;
             if (q >= 0) ph = Phi[q] + step[q] * (double)(idx - pk[q] + 1);
+            else if (ref_on) ph = 0.0 + ref_step * (double)((int64_t)idx - 0 + 1);
             dcx rr = orc_expj(ph);
             win[i] = cmul(y[idx], c32((float)rr.re, (float)rr.im));
           }
@@ -1242,6 +1293,7 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
       }
     }
 
+    if (tap_mask & (1u << OFDM_TAP_RX_SAMPLER)) memcpy(vec_push(&r->sampler, (size_t)N), win, sizeof(ofdm_c32) * (size_t)N);
     /* --- gr.fft_vcc(N, True, [1]*N, True): forward DFT, output halves swapped -- */
     fft_exec(&plan, win, 0);
     for (int k = 0; k < N; k++) Y[k] = win[(k + N / 2) % N];
@@ -1371,6 +1423,9 @@ uint64_t orc_rx_tap(const orc_rx_result *r, int tap, void *out, uint64_t cap_byt
     case OFDM_TAP_RX_FFT: v = &r->fft; break;
     case OFDM_TAP_RX_ACQ: v = &r->acq; break;
     case OFDM_TAP_RX_SINK: v = &r->sink; break;
+    case OFDM_TAP_RX_SAMPLER: v = &r->sampler; break;
+    case OFDM_TAP_RX_SIGMIX: v = &r->sigmix; break;
+    case OFDM_TAP_RX_NCO: v = &r->nco; break;
     case OFDM_TAP_RX_PACKETS: v = &r->raw; break;
     default: return 0;
   }
@@ -1407,6 +1462,9 @@ void orc_rx_free(orc_rx_result *r) {
   vec_free(&r->fft);
   vec_free(&r->acq);
   vec_free(&r->sink);
+  vec_free(&r->sampler);
+  vec_free(&r->sigmix);
+  vec_free(&r->nco);
   vec_free(&r->raw);
   vec_free(&r->raw_off);
   vec_free(&r->payload);

@@ -33,6 +33,9 @@ uint32_t orc_pad_symbol(uint64_t seed, uint64_t pkt, uint64_t slot, uint32_t ari
 int orc_tx(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload_off, const uint32_t *payload_len,
            int npkt, uint64_t lead, ofdm_c32 *iq_out, uint64_t iq_cap, uint64_t *nsamples_out, ofdm_c32 *freq_tap,
            uint8_t *framed_tap, uint64_t *framed_off_tap);
+int orc_tx_ex(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payload_off, const uint32_t *payload_len,
+              int npkt, uint64_t lead, ofdm_c32 *iq_out, uint64_t iq_cap, uint64_t *nsamples_out, ofdm_c32 *freq_tap,
+              uint8_t *framed_tap, uint64_t *framed_off_tap, ofdm_c32 *ifft_tap);
 void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[2]);
 int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0);
 orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint32_t tap_mask);

@@ -49,6 +49,8 @@ def lib():
         L.orc_pad_symbol.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
         L.orc_tx.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, vp, vp, C.c_int, C.c_uint64, vp, C.c_uint64,
                              C.POINTER(C.c_uint64), vp, vp, vp]
+        L.orc_tx_ex.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, vp, vp, C.c_int, C.c_uint64, vp, C.c_uint64,
+                                C.POINTER(C.c_uint64), vp, vp, vp, vp]
         L.orc_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp]
         L.orc_philox.restype = None
         L.orc_channel.argtypes = [vp, C.c_uint64, C.POINTER(_abi.ofdm_chan), C.c_uint64]
@@ -148,9 +150,9 @@ def pack_payloads(payloads):
     return np.ascontiguousarray(blob), offs, lens
 
 
-def tx(cfg, payloads, lead=0, tail=0, want_taps=False):
+def tx(cfg, payloads, lead=0, tail=0, want_taps=False, want_ifft=False):
     """Returns iq (complex64, lead + symbols + tail, zeros outside the symbols) and
-    optionally (freq-domain symbols [nsym, N], framed packets list)."""
+    optionally (freq-domain symbols [nsym, N], framed packets list[, transform output [nsym, N]])."""
     L = lib()
     blob, offs, lens = pack_payloads(payloads)
     N, CP = cfg.fft_length, cfg.cp_length
@@ -170,16 +172,17 @@ def tx(cfg, payloads, lead=0, tail=0, want_taps=False):
     freq = np.zeros((nsym, N), np.complex64) if want_taps else None
     framed = np.zeros(sum(flens) + 1, np.uint8) if want_taps else None
     foff = np.zeros(len(payloads) + 1, np.uint64) if want_taps else None
-    rc = L.orc_tx(C.byref(cfg), _ptr(blob), _ptr(offs), _ptr(lens), len(payloads), lead, _ptr(iq), total,
-                  C.byref(ns), _ptr(freq) if want_taps else None, _ptr(framed) if want_taps else None,
-                  _ptr(foff) if want_taps else None)
+    ifft = np.zeros((nsym, N), np.complex64) if want_ifft else None
+    rc = L.orc_tx_ex(C.byref(cfg), _ptr(blob), _ptr(offs), _ptr(lens), len(payloads), lead, _ptr(iq), total,
+                     C.byref(ns), _ptr(freq) if want_taps else None, _ptr(framed) if want_taps else None,
+                     _ptr(foff) if want_taps else None, _ptr(ifft) if want_ifft else None)
     if rc:
         raise ValueError("orc_tx rc=%d" % rc)
     assert ns.value == lead + nsym * (N + CP)
     if want_taps:
         pk = [framed[int(foff[i]):int(foff[i + 1])].tobytes() for i in range(len(payloads))]
-        return iq, freq, pk
-    return iq
+        return (iq, freq, pk, ifft) if want_ifft else (iq, freq, pk)
+    return (iq, ifft) if want_ifft else iq
 
 
 def channel(iq, sigma=0.0, cfo=0.0, seed=0xC0FFEE, stream_id=0, index0=0):
@@ -194,6 +197,7 @@ _TAP_DTYPES = {
     _abi.TAP_RX_CHAN_FILT: np.complex64, _abi.TAP_RX_METRIC: np.float32, _abi.TAP_RX_PEAKS: np.uint64,
     _abi.TAP_RX_ANGLES: np.float32, _abi.TAP_RX_FRAMES: np.uint64, _abi.TAP_RX_FFT: np.complex64,
     _abi.TAP_RX_ACQ: np.complex64, _abi.TAP_RX_SINK: np.complex64, _abi.TAP_RX_PACKETS: np.uint8,
+    _abi.TAP_RX_SAMPLER: np.complex64, _abi.TAP_RX_SIGMIX: np.complex64, _abi.TAP_RX_NCO: np.complex64,
 }
 
 
@@ -223,7 +227,7 @@ class RxResult(object):
             lib().orc_rx_tap(self._h, tap, _ptr(out), nb)
         if tap == _abi.TAP_RX_FRAMES:
             out = out.reshape(-1, 2)
-        elif tap == _abi.TAP_RX_FFT:
+        elif tap in (_abi.TAP_RX_FFT, _abi.TAP_RX_SAMPLER):
             out = out.reshape(-1, self._cfg.fft_length)
         elif tap in (_abi.TAP_RX_ACQ, _abi.TAP_RX_SINK):
             out = out.reshape(-1, self._cfg.occupied_tones)

@@ -47,7 +47,7 @@ def test_struct_layout_matches_header(tmp_path):
         assert int(got[name]) == ctypes.sizeof(st), name
         for f, _ in st._fields_:
             assert int(got["%s.%s" % (name, f)]) == getattr(st, f).offset, (name, f)
-    assert ctypes.sizeof(_abi.ofdm_cfg) == 41040 + 1032
+    assert ctypes.sizeof(_abi.ofdm_cfg) == 41040 + 1032 + 16   # (+ sync_mode, fixed_nsymbols, fixed_freq_offset, reserved0)
 
 
 def test_create_rejects_bad_abi_or_config_without_a_gpu():

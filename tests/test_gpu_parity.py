@@ -144,6 +144,87 @@ def test_partial_nibble_sizes_parity(orc, mod, N, occ, CP):
     eng.close()
 
 
+def test_log_probe_taps(orc):
+    """The remaining --log probe points of the reference (ofdm.py:124-130, ofdm_receiver.py~:149-152): mapper
+    output, transform output, sampler output, sigmix and nco streams -- every one bit-identical to the oracle."""
+    cfg = make_cfg("qam16", 256, 120, 64)
+    eng = _engine(cfg)
+    pay = make_payloads(4, [90, 400, 17, 250], seed=8)
+    eng.set_taps(_abi.TAP_TX_FREQ, _abi.TAP_TX_MAPPER, _abi.TAP_TX_IFFT)
+    iq_g = eng.tx(pay)
+    iq_o, freq_o, framed, ifft_o = orc.tx(cfg, pay, want_taps=True, want_ifft=True)
+    assert np.array_equal(iq_g, iq_o)
+    assert np.array_equal(eng.tap(_abi.TAP_TX_IFFT), ifft_o)
+    # the mapper's own output = every symbol but the preamble insert_preamble adds in front of each packet
+    ncar = len(config.carrier_map(120, 256))
+    first, keep = 0, []
+    for f in framed:
+        nds = -(-8 * len(f) // (ncar * 4))
+        keep += list(range(first + 1, first + 1 + nds))
+        first += 1 + nds
+    assert np.array_equal(eng.tap(_abi.TAP_TX_MAPPER), freq_o[keep])
+    N, CP = 256, 64
+    # the two multiply_const blocks behind the cyclic prefixer (ofdm.py:114, transmit_path.py:48-54)
+    assert np.array_equal(iq_g.reshape(-1, N + CP)[:, CP:], ifft_o * np.float32(1.0 / np.sqrt(N)) * np.float32(cfg.tx_amplitude))
+    x = loopback_stream(orc, cfg, pay, snr_db=32.0, cfo_bins=0.2)
+    taps = (_abi.TAP_RX_SAMPLER, _abi.TAP_RX_SIGMIX, _abi.TAP_RX_NCO, _abi.TAP_RX_FFT)
+    ro = orc.rx(cfg, x, sum(1 << t for t in taps))
+    eng.set_taps(*taps)
+    assert eng.rx(x) == ro.packets
+    for t in taps:
+        assert np.array_equal(eng.tap(t), ro.tap(t), equal_nan=True), t
+    # a16 on its own: sigmix = chan_filt * nco, |nco| = 1, and the sampler's symbols are the sigmix samples it picked
+    # (closed form vs the receiver's float64 recurrence: at most the last float32 bit apart)
+    nco, sm, samp = eng.tap(_abi.TAP_RX_NCO), eng.tap(_abi.TAP_RX_SIGMIX), eng.tap(_abi.TAP_RX_SAMPLER)
+    assert np.abs(np.abs(nco) - 1.0).max() < 2e-7
+    fr = eng.tap(_abi.TAP_RX_FRAMES)
+    row = 0
+    for p, K in fr:
+        for k in range(int(K) + 1):
+            s0 = int(p) - N + 1 + k * (N + CP)
+            ref = sm[s0:s0 + N]
+            assert np.abs(samp[row] - ref).max() <= 4e-7 * max(1.0, float(np.abs(ref).max()))
+            row += 1
+    assert row == len(samp)
+    eng.close()
+
+
+@pytest.mark.parametrize("fo_bins", [0.0, 0.2])
+def test_sync_fixed_parity(orc, fo_bins):
+    """SYNC = "fixed" (ofdm_receiver.py~:108-119, "for testing only"): no channel filter, a flag on the last sample
+    of every nsymbols-th symbol, a constant frequency offset into the NCO."""
+    N, CP = 512, 128
+    probe = make_cfg("qpsk", N, 200, CP)
+    pay = make_payloads(6, 500, seed=21)
+    nsym = len(orc.tx(probe, pay[:1])) // (N + CP)                  # symbols per packet incl. the preamble
+    from ofdm_uhd_amd import options
+    opt = options.default_options(modulation="qpsk", fft_length=N, occupied_tones=200, cp_length=CP, sync="fixed",
+                                  sync_nsymbols=nsym, sync_freq_offset=float(np.pi * fo_bins))
+    cfg = config.make_cfg(opt)
+    eng = _engine(cfg)
+    x = loopback_stream(orc, cfg, pay, snr_db=30.0, cfo_bins=fo_bins, lead=0, tail=700)
+    taps = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_SAMPLER, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK, _abi.TAP_RX_PACKETS,
+            _abi.TAP_RX_NCO)
+    ro = orc.rx(cfg, x, sum(1 << t for t in taps))
+    eng.set_taps(*taps)
+    pk = eng.rx(x)
+    assert pk == ro.packets and [p for ok, p in pk if ok] == pay
+    assert eng.tap(_abi.TAP_RX_PEAKS).tolist() == ro.tap(_abi.TAP_RX_PEAKS).tolist() == [
+        N + CP - 1 + k * nsym * (N + CP) for k in range(6 + (700 >= N + CP))]
+    assert np.array_equal(eng.tap(_abi.TAP_RX_CHAN_FILT), x)        # gr.multiply_const_cc(1.0)
+    assert np.array_equal(eng.tap(_abi.TAP_RX_ANGLES), ro.tap(_abi.TAP_RX_ANGLES))
+    assert eng.tap(_abi.TAP_RX_FRAMES).tolist() == ro.tap(_abi.TAP_RX_FRAMES).tolist()
+    for t in taps:
+        assert np.array_equal(eng.tap(t), ro.tap(t), equal_nan=True), t
+    for k in ("symbols", "samples", "peaks", "frames", "headers_ok", "packets", "crc_ok", "chained_frames"):
+        assert eng.last_stats[k] == ro.stats[k], k
+    with pytest.raises(ValueError):
+        eng.set_taps(_abi.TAP_RX_METRIC)
+        eng.rx(x)
+        eng.tap(_abi.TAP_RX_METRIC)
+    eng.close()
+
+
 def _sensed_maps():
     import json
     import os

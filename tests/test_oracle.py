@@ -187,3 +187,26 @@ def test_deterministic_sincos_accuracy(orc):
     z = orc.expj(ph)
     red = ph - 2 * np.pi * np.floor(ph / (2 * np.pi) + 0.5)
     assert np.abs(z - np.exp(1j * red)).max() < 4e-16
+
+
+def test_sync_fixed_oracle_loopback(orc):
+    """SYNC = "fixed" in the oracle: flags at (N+CP)-1 + k*nsymbols*(N+CP), chan_filt = x, constant NCO input."""
+    from ofdm_uhd_amd import options
+    N, CP = 256, 64
+    pay = make_payloads(5, 300, seed=4)
+    nsym = len(orc.tx(make_cfg("qpsk", N, 120, CP), pay[:1])) // (N + CP)
+    for fo_bins in (0.0, -0.3):
+        opt = options.default_options(modulation="qpsk", fft_length=N, occupied_tones=120, cp_length=CP, sync="fixed",
+                                      sync_nsymbols=nsym, sync_freq_offset=float(np.pi * fo_bins))
+        cfg = config.make_cfg(opt)
+        x = loopback_stream(orc, cfg, pay, snr_db=30.0, cfo_bins=fo_bins, lead=0, tail=100)
+        r = orc.rx(cfg, x, (1 << _abi.TAP_RX_CHAN_FILT) | (1 << _abi.TAP_RX_NCO))
+        assert np.array_equal(r.tap(_abi.TAP_RX_CHAN_FILT), x)
+        assert list(r.tap(_abi.TAP_RX_PEAKS)) == [N + CP - 1 + k * nsym * (N + CP) for k in range(5)]
+        assert [p for ok, p in r.packets if ok] == pay
+        # gr_frequency_modulator_fc driven by a constant: phi[n] = -2/N * f * (n+1)
+        n = np.arange(len(x))
+        want = np.exp(1j * (-2.0 / N) * np.float32(np.pi * fo_bins) * (n + 1))
+        assert np.abs(r.tap(_abi.TAP_RX_NCO) - want).max() < 2e-6
+    with pytest.raises(ValueError):
+        config.make_cfg(options.default_options(sync="ml"))
