@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--cpu-packets", type=int, default=4096, help="sample size of the CPU baseline (0 = skip)")
     ap.add_argument("--sense", default="auto", choices=("auto", "on", "off"),
                     help="fuse the predictive_sense.py spectrum sensor into every RX call (auto: on for c5)")
+    ap.add_argument("--sync", default="pn", choices=("pn", "fixed"),
+                    help="receiver front end: 'pn' = the reference's Schmidl-Cox chain (default, the headline number); "
+                         "'fixed' = its known-timing test mode (ofdm_receiver.py~:108-119): no filter, no metric -- "
+                         "times the rest of the receiver on its own")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="BASELINE.json config to run (default c2 = configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
@@ -175,17 +179,24 @@ def main():
     if args.snr is None:
         args.snr = cfgd["snr"]
     opt = options.default_options(modulation=mod, fft_length=N, occupied_tones=occ, cp_length=CP, tx_amplitude=0.25)
-    cfg = config.make_cfg(opt, device_ptrs=True, device_id=local_rank)
-    eng = engine.Engine(cfg=cfg)
     L = N + CP
     P, size = args.packets, args.size
+    if args.sync == "fixed":
+        # ofdm_sync_fixed flags the last sample of every nsymbols-th symbol counted from the first sample: the stream
+        # starts on a preamble (no lead-in) and every packet has the same length
+        probe = engine.Engine(cfg=config.make_cfg(opt, device_ptrs=True, device_id=local_rank))
+        nsym1, _ = probe.tx_frame_count(np.full(1, size, np.uint32))
+        probe.close()
+        opt.sync, opt.sync_nsymbols, opt.sync_freq_offset = "fixed", int(nsym1), 0.0
+    cfg = config.make_cfg(opt, device_ptrs=True, device_id=local_rank)
+    eng = engine.Engine(cfg=cfg)
     stream_id = rank
     ncar = len(config.carrier_map(occ, N))
     # mean in-packet power: ncar carriers of mean constellation power through IFFT/sqrt(N), amplitude 0.25
     cpow = float(np.mean(np.abs(np.array(config.rotated_constellation(mod))) ** 2))
     psig = ncar / float(N) * 0.25 ** 2 * cpow
     sigma = float(np.sqrt(psig / 10 ** (args.snr / 10.0)))
-    lead, tail = 2 * N, L + 2 * N
+    lead, tail = (0, 2 * N) if args.sync == "fixed" else (2 * N, L + 2 * N)
     eng.set_channel(sigma=sigma, cfo=0.0, seed=0xC0FFEE, stream_id=stream_id, lead=lead, tail=tail)
 
     blob = make_payload_blob(P, size, stream_id)
@@ -311,7 +322,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": cfgd["name"],
+            "config": {"workload": cfgd["name"] + ("" if args.sync == "pn" else " -- SYNC='fixed' test mode (no filter / metric)"),
                        "packets_per_stream_per_step": P, "payload_bytes": size, "symbols_per_packet": nsym // P,
                        "snr_db": args.snr, "streams": world, "parallelism": "independent streams, 1 per GPU"},
             "crc_pass_rate": g["crc_ok"] / float(max(world * P * args.steps, 1)),

@@ -318,13 +318,14 @@ enum {
   OFDM_K_FRAME = 0, /* make_packet: CRC-32 + header + whitening              */
   OFDM_K_TX = 1,    /* map + preamble + IFFT + CP + scale (+channel)         */
   OFDM_K_CHAN = 2,  /* standalone channel                                    */
-  OFDM_K_SYNC = 3,  /* Schmidl-Cox metric + candidates                       */
+  OFDM_K_SYNC = 3,  /* Schmidl-Cox metric, float32 pre-selection (streaming) */
   OFDM_K_PEAK = 4,  /* peak detector / sampler / NCO bookkeeping             */
   OFDM_K_DEMOD = 5, /* derotate + FFT + frame acquisition + frame sink       */
   OFDM_K_DEFRAME = 6, /* dewhiten + CRC check + output compaction            */
   OFDM_K_SENSE = 7, /* windowed FFT + |.|^2 + max-hold (+ decision tail)    */
   OFDM_K_FILTER = 8, /* channel filter (overlap-save transforms, streaming)  */
-  OFDM_K_COUNT = 9
+  OFDM_K_EXACT = 9,  /* fixed-point metric + candidates where the pre-selection fired */
+  OFDM_K_COUNT = 10
 };
 int ofdm_prof_enable(ofdm_handle *h, int on);
 int ofdm_prof_reset(ofdm_handle *h);

@@ -30,7 +30,7 @@ OFDM_F_PAD_FOR_USRP = 1 << 1
  TAP_RX_SIGMIX, TAP_RX_NCO, TAP_COUNT) = range(17)
 SYNC_PN, SYNC_FIXED = 0, 1
 
-(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_COUNT) = range(10)
+(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_EXACT, K_COUNT) = range(11)
 OFDM_SENSE_MAX_FFT = 4096
 
 

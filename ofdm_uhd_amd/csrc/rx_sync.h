@@ -44,6 +44,13 @@ struct SyncPiece {
   double bloc;       // zero-initialised running average over the tile's samples before `start`
 };
 
+// a tile whose float32 metric came near the threshold: work item of k_sync_exact
+struct SyncRec {
+  uint64_t tile;
+  int amin, bmax;      // range of the approximate candidates, tile-relative
+  float gpre, gpost;   // float32 detector summary of the samples before amin / after bmax, weighted to the tile's end
+};
+
 struct SyncParams {
   int N, D, CP;
   int HY;         // y history the metric needs before a tile (2*D + CP, multiple of 8)
@@ -74,6 +81,8 @@ struct SyncParams {
   uint64_t cand_cap;
   unsigned long long* cand_count;  // device counter
   unsigned int* overflow;          // device flag
+  SyncRec* recs;                   // [ntiles]
+  unsigned long long* rec_count;   // device counter
 };
 
 __host__ __device__ inline int sync_lp(int i) { return i + (i >> 3); }
@@ -168,27 +177,38 @@ __global__ void __launch_bounds__(256, 3) k_chan_filter(FilterParams p) {
 }
 
 struct SyncLds {
-  size_t ys, work, mt, me, ue, mh, misc, total;
+  size_t ys, mt, mh, misc, total;
 };
-// LDS: the ring of filtered samples | the tile's M values (mt; later the exact u, ue) and -- rare path -- the
-// exact M (me) | the CP newest M values of the previous tile (mh) | scan / vote scratch.
-__host__ __device__ inline SyncLds sync_lds_layout(int R, int HM, int CP) {
+// LDS of k_sync: the ring of filtered samples | the tile's M values (mt) | the CP newest M values of the previous
+// tile (mh) | scan / vote scratch.
+__host__ __device__ inline SyncLds sync_lds_layout(int R, int HM) {
   SyncLds l;
   size_t o = 0;
   l.ys = o;
   o += (size_t)(sync_lp(R) + 2) * sizeof(c32);
   o = (o + 15) & ~(size_t)15;
-  l.work = o;
-  l.mt = o;  // M of the tile; later: exact u over [amin, bmax] (needs SYNC_TILE + 8 floats)
-  l.ue = o;
-  const size_t mt_bytes = ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
-  const size_t me_bytes = ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
-  l.me = o + mt_bytes;  // exact M over [amin-CP+1, bmax]
-  o += mt_bytes + me_bytes;
+  l.mt = o;
+  o += ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
   l.mh = o;  // M history: the CP values before the tile
   o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
   l.misc = o;
-  o += 1024;
+  o += 256;
+  l.total = o;
+  return l;
+}
+// LDS of k_sync_exact: exact M over [amin-CP+1, bmax] (me) | exact u over [amin, bmax] (ue) | scan scratch
+struct ExactLds {
+  size_t me, ue, misc, total;
+};
+__host__ __device__ inline ExactLds exact_lds_layout(int CP) {
+  ExactLds l;
+  size_t o = 0;
+  l.me = o;
+  o += ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
+  l.ue = o;
+  o += ((size_t)(SYNC_TILE + 8) * sizeof(float) + 15) & ~(size_t)15;
+  l.misc = o;
+  o += 512;
   l.total = o;
   return l;
 }
@@ -348,16 +368,17 @@ __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scra
 // Rare path (only where the float32 pre-selection found something): kept out of line so that it
 // does not weigh on the register allocation of the streaming loop.
 // ---------------------------------------------------------------------------------
-__device__ __noinline__ void sync_exact_range(const c32* ys, float* me, float* ue, c32* gP, float* gU, long long* sc_i64, int amin,
-                                              int bmax, int D, int CP, int rbase, int R, int64_t t0s, int64_t qvalid, int64_t mvalid,
-                                              float tapcp) {
+__device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, float* me, float* ue, c32* gP, float* gU, long long* sc_i64,
+                                                 int amin, int bmax, int D, int CP, int64_t t0s, int64_t qvalid, int64_t mvalid,
+                                                 float tapcp) {
   const int tid = threadIdx.x;
 #define QTERM(m)                                                                   \
   ([&]() -> Q3 {                                                                   \
     Q3 q_ = {0, 0, 0};                                                             \
     if (t0s + (int64_t)(m) >= qvalid) {                                            \
-      const c32 a_ = ys[sync_lp(ring_wrap(rbase + (m), R))];                       \
-      const c32 d_ = ys[sync_lp(ring_wrap(rbase + (m) - D, R))];                   \
+      const int64_t ia_ = t0s + (int64_t)(m);   /* y before the stream start reads as zero */ \
+      const c32 a_ = ia_ >= 0 ? y[ia_] : mk(0.f, 0.f);                             \
+      const c32 d_ = ia_ >= D ? y[ia_ - D] : mk(0.f, 0.f);                         \
       const c32 c_ = cmul_conj(a_, d_);                                            \
       q_.pr = q40_clamped(c_.re);                                                  \
       q_.pi = q40_clamped(c_.im);                                                  \
@@ -467,22 +488,15 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   const int tid = threadIdx.x;
   constexpr int T = SYNC_TILE;
   const int R = p.R;
-  const SyncLds L = sync_lds_layout(R, p.HM, p.CP);
+  const SyncLds L = sync_lds_layout(R, p.HM);
   c32* ys = reinterpret_cast<c32*>(smem + L.ys);
   float* mh = reinterpret_cast<float*>(smem + L.mh);
   float* mt = reinterpret_cast<float*>(smem + L.mt);
-  float* me = reinterpret_cast<float*>(smem + L.me);
-  float* ue = reinterpret_cast<float*>(smem + L.ue);
   unsigned char* misc = smem + L.misc;
-  long long* sc_i64 = reinterpret_cast<long long*>(misc);      // 24 entries
-  double* sc_f64 = reinterpret_cast<double*>(misc + 192);      // 2 * 5 entries
-  int* sc_i32 = reinterpret_cast<int*>(misc + 272);            // 5 entries
-  unsigned char* cm = misc + 320;                               // 256 candidate masks
-  unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 576);  // 2 broadcast words (chunk allocation)
-  float* scA = reinterpret_cast<float*>(misc + 608);           // 24 floats
-  float* scB = reinterpret_cast<float*>(misc + 704);           // 8 floats
-  float* scC = reinterpret_cast<float*>(misc + 736);           // 4 floats
-  int* rng = reinterpret_cast<int*>(misc + 752);               // [0] amin, [1] bmax
+  float* scA = reinterpret_cast<float*>(misc);                 // 24 floats
+  float* scB = reinterpret_cast<float*>(misc + 96);            // 8 floats
+  float* scC = reinterpret_cast<float*>(misc + 128);           // 4 floats
+  int* rng = reinterpret_cast<int*>(misc + 144);               // [0] amin, [1] bmax
 
   const uint64_t seg = blockIdx.x;
   const uint64_t tile_own0 = seg * (uint64_t)p.tiles_per_seg;
@@ -503,9 +517,6 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   // weight of this thread's 8 samples in the tile summary of the detector average
   const float decay_f = (float)p.decay;
   const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
-  // current allocation chunks of this workgroup (uniform across the block)
-  unsigned long long cand_base = 0, piece_base = 0;
-  uint32_t cand_left = 0, piece_left = 0;
   int rbase = 0;  // the ring slot of the tile's first sample
   // the next tile of y, fetched a tile ahead: its HBM latency hides behind the metric phase
   float4 ypre[SYNC_V / 2];
@@ -729,7 +740,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     }
     if (!anyc) continue;  // (a tile with candidates gets its summary below, from the exact values)
 
-    // ================= rare path: something near the threshold in this tile =================
+    // ================= something near the threshold in this tile: leave a record for k_sync_exact ============
+    // The fixed-point re-evaluation of the range [amin, bmax], the candidate pieces and the tile's detector summary
+    // are k_sync_exact's work (one workgroup per record, all records in parallel); this kernel only adds what it
+    // alone knows: the float32 summary of the samples before and after the range, weighted to the tile's end.
     if (tl == 0) {
       rng[0] = T;
       rng[1] = -1;
@@ -741,12 +755,93 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     }
     __syncthreads();
     const int amin = rng[0], bmax = rng[1];
+    float fpre = 0.f, fpost = 0.f;
+#pragma unroll
+    for (int j = 0; j < SYNC_V; j++) {
+      if (j < nv) {
+        const int i = SYNC_V * tl + j;
+        fpre = fmaf(fpre, decay_f, p.alpha * ((i < amin) ? u[j] : 0.0f));
+        fpost = fmaf(fpost, decay_f, p.alpha * ((i > bmax) ? u[j] : 0.0f));
+      }
+    }
+    {
+      const float a = wave_incl_scan_f32(fpre * wgt), b = wave_incl_scan_f32(fpost * wgt);
+      if (lane_id() == WAVE - 1) {
+        scA[2 * wave_id()] = a;
+        scA[2 * wave_id() + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tl == 0) {
+      float ga = 0.f, gb = 0.f;
+#pragma unroll
+      for (int w = 0; w < SYNC_THREADS / WAVE; w++) {
+        ga += scA[2 * w];
+        gb += scA[2 * w + 1];
+      }
+      const unsigned long long r = atomicAdd(p.rec_count, 1ull);  // (capacity: one record per tile)
+      SyncRec rec;
+      rec.tile = tile;
+      rec.amin = amin;
+      rec.bmax = bmax;
+      rec.gpre = ga;
+      rec.gpost = gb;
+      p.recs[r] = rec;
+    }
     STAMP(8);
-    // ---- 7. fixed-point re-evaluation of [amin, bmax] (normative arithmetic); the whole range is
-    //         stored as this tile's candidate values (u, P), pieces then point into it -------------------
+  }
+#ifdef SYNC_STAMPS
+  if (p.stamps && threadIdx.x == 0)
+    for (int i = 0; i < 16; i++) p.stamps[blockIdx.x * 16 + i] = st_acc[i];
+#endif
+}
+
+// ---------------------------------------------------------------------------------
+// k_sync_exact: the tiles k_sync found something near the threshold in (about one in five at C2).  One workgroup per
+// record, records taken round-robin from the list (its length is read on the device: no host round trip):
+//   7. fixed-point (Q23.40, normative) re-evaluation of u and P over [amin, bmax], y read straight from HBM / L2;
+//      the whole range becomes the tile's candidate values;
+//   8. candidate pieces = maximal runs of exact u > theta, each with the tile-local detector average before it; the
+//      tile's detector summary from the values just used: exact u inside the range, k_sync's float32 partial sums
+//      outside.  (Where the window energy drops by 50-60 dB inside a tile the float32 sums lose the small R to
+//      cancellation -- M is then large AND a few percent off, enough to move the average later tiles inherit.)
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SYNC_THREADS) k_sync_exact(SyncParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int T = SYNC_TILE;
+  const int tl = threadIdx.x;
+  const ExactLds L = exact_lds_layout(p.CP);
+  float* me = reinterpret_cast<float*>(smem + L.me);
+  float* ue = reinterpret_cast<float*>(smem + L.ue);
+  unsigned char* misc = smem + L.misc;
+  long long* sc_i64 = reinterpret_cast<long long*>(misc);      // 24 entries
+  double* sc_f64 = reinterpret_cast<double*>(misc + 192);      // 2 * 5 entries
+  int* sc_i32 = reinterpret_cast<int*>(misc + 272);            // 5 entries
+  unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 320);  // 2 broadcast words (chunk allocation)
+  const int D = p.D, CP = p.CP;
+  const unsigned long long nrec = *p.rec_count;
+  // current allocation chunks of this workgroup (uniform across the block)
+  unsigned long long cand_base = 0, piece_base = 0;
+  uint32_t cand_left = 0, piece_left = 0;
+
+  for (unsigned long long ri = blockIdx.x; ri < nrec; ri += gridDim.x) {
+    const SyncRec rec = p.recs[ri];
+    const uint64_t tile = rec.tile;
+    const int amin = rec.amin, bmax = rec.bmax;
+    const uint64_t t0 = tile * (uint64_t)T;
+    const int64_t t0s = (int64_t)t0;
+    // the segment this tile was walked in: samples before its warm-up start count as unknown (k_sync's masks)
+    const uint64_t seg = tile / (uint64_t)p.tiles_per_seg;
+    const bool warm = seg > 0;
+    const uint64_t ws = warm ? (seg * (uint64_t)p.tiles_per_seg - (uint64_t)p.nwarm) * (uint64_t)T : 0;
+    const int64_t qvalid = warm ? (int64_t)(ws + (uint64_t)D) : 0;
+    const int64_t mvalid = warm ? (int64_t)(ws + 2ull * (uint64_t)D) - 1 : 0;
+    const int Tl = (t0 + (uint64_t)T <= p.nsamples) ? T : (int)(p.nsamples - t0);  // samples of this tile
+
+    // ---- 7. fixed-point re-evaluation of [amin, bmax]; stored as this tile's candidate values (u, P) ----
     const int rlen = bmax - amin + 1;
     if ((uint32_t)rlen > cand_left) {
-      if (tl == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);  // rare: fresh chunk
+      if (tl == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);  // fresh chunk
       __syncthreads();
       cand_base = bc[0];
       cand_left = SYNC_CHUNK_C;
@@ -757,36 +852,26 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     cand_base += (unsigned long long)rlen;
     cand_left -= (uint32_t)rlen;
     if (fits) {
-      sync_exact_range(ys, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, rbase, R, t0s, qvalid, mvalid,
-                       p.tapcp);
+      sync_exact_range(p.y, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, t0s, qvalid, mvalid, p.tapcp);
     } else {
       for (int i = tl; i < rlen; i += SYNC_THREADS) ue[i] = -1.0f;  // nothing can be stored: no candidates
       __syncthreads();
     }
-    STAMP(9);
 
-    // ---- 8. candidates: maximal runs of (exact) u > theta inside the tile ----------------------
-    unsigned cmask = 0;
-#pragma unroll
-    for (int j = 0; j < SYNC_V; j++) {
-      const int i = SYNC_V * tl + j;
-      if (j < nv && i >= amin && i <= bmax) {
-        const float ux = ue[i - amin];
-        u[j] = ux;
-        if (ux > p.cand_thr) cmask |= 1u << j;
-        if (p.metric_tap) p.metric_tap[t0 + (uint64_t)i] = ux;
-      }
-    }
-    // running average before each sample of this thread (zero-initialised at the tile start)
+    // ---- 8. pieces and summary: each thread walks lc consecutive samples of the range ----
+    const int lc = (rlen + SYNC_THREADS - 1) / SYNC_THREADS;
+    const int j0 = tl * lc, j1 = (j0 + lc < rlen) ? (j0 + lc) : rlen;
     Aff f;
     f.A = 1.0;
     f.b = 0.0;
-#pragma unroll
-    for (int j = 0; j < SYNC_V; j++)
-      if (j < nv) {
-        f.A = f.A * p.decay;
-        f.b = (double)p.alpha * (double)u[j] + p.decay * f.b;
-      }
+    int nstart = 0;
+    for (int k = j0; k < j1; k++) {
+      const float ux = ue[k];
+      f.A = f.A * p.decay;
+      f.b = (double)p.alpha * (double)ux + p.decay * f.b;
+      if (ux > p.cand_thr && !(k > 0 && ue[k - 1] > p.cand_thr)) nstart++;
+      if (p.metric_tap) p.metric_tap[t0 + (uint64_t)(amin + k)] = ux;
+    }
     Aff inc = f;
     {
       const int lane = lane_id(), w = wave_id();
@@ -802,18 +887,18 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
         sc_f64[2 * w + 1] = inc.b;
       }
     }
-    cm[tl] = (unsigned char)cmask;
     __syncthreads();
-    Aff pre;
-    pre.A = 1.0;
-    pre.b = 0.0;
+    Aff pre, tot;
+    pre.A = tot.A = 1.0;
+    pre.b = tot.b = 0.0;
     {
       const int w = wave_id();
-      for (int i = 0; i < w; i++) {
+      for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
         Aff g;
         g.A = sc_f64[2 * i];
         g.b = sc_f64[2 * i + 1];
-        pre = aff_then(pre, g);
+        if (i < w) pre = aff_then(pre, g);
+        tot = aff_then(tot, g);
       }
       Aff prev;
       prev.A = __shfl_up(inc.A, 1, WAVE);
@@ -824,24 +909,13 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
       pre = aff_then(pre, prev);
     }
-    // Tile summary of the detector's average from the values just used: exact u wherever the metric is near
-    // or above the threshold, float32 only where it is small.  (Where the window energy drops by 50-60 dB inside
-    // a tile the float32 sums lose the small R to cancellation -- M = |P|^2/R^2 is then large AND a few percent
-    // off, enough to move the average that later tiles inherit.)
-    if (tl == SYNC_THREADS - 1) p.tile_B[tile] = aff_then(pre, f).b;
-    const unsigned prevbit = (tl > 0) ? ((cm[tl - 1] >> 7) & 1u) : 0u;
-    const unsigned nextbit = (tl < SYNC_THREADS - 1) ? (cm[tl + 1] & 1u) : 0u;
-    const unsigned ext = (cmask << 1) | prevbit;           // bit j+1 = cand[j], bit 0 = cand[-1]
-    const unsigned startmask = cmask & ~ext & 0xFFu;       // cand[j] && !cand[j-1]
-    const unsigned extn = (cmask >> 1) | (nextbit << 7);   // bit j = cand[j+1]
-    const unsigned endmask = cmask & ~extn & 0xFFu;        // cand[j] && !cand[j+1]
-    const int packed = (__popc(startmask) << 16) | __popc(cmask);
+    // the detector average (zero at the tile start) just before amin, from k_sync's float32 sum weighted to the tile's end
+    const double a0 = (double)rec.gpre * pow(p.decay, -(double)(Tl - amin));
     int ptot;
-    const int pex = block_excl_scan_add<int>(packed, sc_i32, &ptot);
-    const int nstart_before = pex >> 16;
-    const int npieces = ptot >> 16, ncand = ptot & 0xFFFF;
+    const int nstart_before = block_excl_scan_add<int>(nstart, sc_i32, &ptot);
+    const int npieces = ptot;
     if ((uint32_t)npieces > piece_left) {
-      if (tl == 0) bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);  // rare: fresh chunk
+      if (tl == 0) bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);  // fresh chunk
       __syncthreads();
       piece_base = bc[1];
       piece_left = SYNC_CHUNK_P;
@@ -849,25 +923,27 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     const unsigned long long basep = piece_base;
     fits = fits && (basep + (unsigned long long)npieces <= p.piece_cap);
     if (!fits && tl == 0) atomicOr(p.overflow, 1u);
-    if (fits && ncand > 0) {
-      double a_loc = pre.b;  // zero-init average just before this thread's first sample
+    if (fits && npieces > 0) {
+      double a_loc = pre.A * a0 + pre.b;  // average just before this thread's first sample
       int so = nstart_before;
-#pragma unroll
-      for (int j = 0; j < SYNC_V; j++) {
-        const int i = SYNC_V * tl + j;
-        const uint64_t n = t0 + (uint64_t)i;
-        if ((startmask >> j) & 1u) {
+      for (int k = j0; k < j1; k++) {
+        const float ux = ue[k];
+        const bool cand = ux > p.cand_thr;
+        const uint64_t n = t0 + (uint64_t)(amin + k);
+        if (cand && !(k > 0 && ue[k - 1] > p.cand_thr)) {
           SyncPiece* pc = p.pieces + basep + so;
           pc->start = n;
-          pc->val_off = cbase + (unsigned long long)(i - amin);
+          pc->val_off = cbase + (unsigned long long)k;
           pc->bloc = a_loc;
           so++;
         }
-        if ((endmask >> j) & 1u) p.pieces[basep + so - 1].end = n;
-        if (j < nv) a_loc = (double)p.alpha * (double)u[j] + p.decay * a_loc;
+        if (cand && !(k + 1 < rlen && ue[k + 1] > p.cand_thr)) p.pieces[basep + so - 1].end = n;
+        a_loc = (double)p.alpha * (double)ux + p.decay * a_loc;
       }
     }
     if (tl == 0) {
+      // average after bmax, carried to the tile's end, plus what follows the range
+      p.tile_B[tile] = (tot.A * a0 + tot.b) * pow(p.decay, (double)(Tl - 1 - bmax)) + (double)rec.gpost;
       p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
       p.tile_first[tile] = basep;
     }
@@ -875,13 +951,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       piece_base += (unsigned long long)npieces;
       piece_left -= (uint32_t)npieces;
     }
-    __syncthreads();  // ue / me are scratch that the next iteration overwrites
-    STAMP(10);
+    __syncthreads();  // ue / me / scratch are reused by the next record
   }
-#ifdef SYNC_STAMPS
-  if (p.stamps && threadIdx.x == 0)
-    for (int i = 0; i < 16; i++) p.stamps[blockIdx.x * 16 + i] = st_acc[i];
-#endif
 }
 
 // ---------------------------------------------------------------------------------
