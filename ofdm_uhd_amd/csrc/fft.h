@@ -92,6 +92,90 @@ __device__ __forceinline__ void dft2(c32& v0, c32& v1) {
   v1 = d;
 }
 
+// ---- the same butterflies on packed registers -------------------------------------------------------------
+// A complex value in an even-aligned VGPR pair lets one v_pk_*_f32 do both parts.  clang finds the packed adds and
+// scalings by itself but not the two shapes below -- "add the other operand rotated by -/+ 90 degrees" and the
+// complex product with its explicit fma placement -- so they are spelled out with VOP3P operand selection (op_sel /
+// op_sel_hi pick the half of each source per result half, neg_lo / neg_hi negate it).  Every result has the bits of
+// the scalar code above (negations and operand swaps are exact): only the instruction count changes -- radix-8
+// butterfly 26 instead of ~60, twiddle product 2 instead of 4.  Used where the transform is all a kernel does
+// (k_chan_filter); in kernels bound by other work the asm blocks cost the scheduler more than they save
+// (tools/experiments/README.md).
+typedef float cv __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cv cv_of(c32 a) {
+  cv r;
+  r.x = a.re;
+  r.y = a.im;
+  return r;
+}
+__device__ __forceinline__ c32 c32_of(cv a) { return mk(a.x, a.y); }
+// x + (-i) y = (x.re + y.im, x.im - y.re)
+__device__ __forceinline__ cv pk_add_mi(cv x, cv y) {
+  cv r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+// x + (+i) y = (x.re - y.im, x.im + y.re)
+__device__ __forceinline__ cv pk_add_pi(cv x, cv y) {
+  cv r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+template <bool INV>
+__device__ __forceinline__ cv pk_rot_add(cv x, cv y) {  // x + (-/+ i) y   (forward: -i, inverse: +i)
+  return INV ? pk_add_pi(x, y) : pk_add_mi(x, y);
+}
+template <bool INV>
+__device__ __forceinline__ cv pk_rot_sub(cv x, cv y) {  // x - (-/+ i) y
+  return INV ? pk_add_mi(x, y) : pk_add_pi(x, y);
+}
+// cmul_f(a, w) for the forward transform, cmul_f(a, conj(w)) for the inverse, w from the forward table:
+//   re = fma(a.re, w.re, -/+ a.im*w.im)    im = fma(a.re, +/- w.im, a.im*w.re)
+template <bool INV>
+__device__ __forceinline__ cv pk_cmul_tw(cv a, cv w) {
+  cv t, r;
+  if (INV) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  } else {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  }
+  return r;
+}
+template <bool INV>
+__device__ __forceinline__ void dft8_pk(cv v[8]) {
+  const float h = 0.70710678118654752440f;
+  const cv a0 = v[0] + v[4], a4 = v[0] - v[4];
+  const cv a1 = v[1] + v[5], d5 = v[1] - v[5];
+  const cv a2 = v[2] + v[6], a6 = v[2] - v[6];  // a6 still lacks its factor -/+ i: folded into c0, c2
+  const cv a3 = v[3] + v[7], d7 = v[3] - v[7];
+  // odd branch twiddles: w8^1 d5 = h (d5 -/+ i d5),  w8^3 d7 = -h (d7 +/- i d7)
+  const cv a5 = pk_rot_add<INV>(d5, d5) * h;
+  const cv a7 = pk_rot_sub<INV>(d7, d7) * (-h);
+  const cv b0 = a0 + a2, b2 = a0 - a2;
+  const cv b1 = a1 + a3, b3 = a1 - a3;          // b3 lacks -/+ i
+  const cv c0 = pk_rot_add<INV>(a4, a6), c2 = pk_rot_sub<INV>(a4, a6);
+  const cv c1 = a5 + a7, c3 = a5 - a7;          // c3 lacks -/+ i
+  v[0] = b0 + b1;
+  v[4] = b0 - b1;
+  v[2] = pk_rot_add<INV>(b2, b3);
+  v[6] = pk_rot_sub<INV>(b2, b3);
+  v[1] = c0 + c1;
+  v[5] = c0 - c1;
+  v[3] = pk_rot_add<INV>(c2, c3);
+  v[7] = pk_rot_sub<INV>(c2, c3);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4_pk(cv& v0, cv& v1, cv& v2, cv& v3) {
+  const cv s0 = v0 + v2, d0 = v0 - v2;
+  const cv s1 = v1 + v3, d1 = v1 - v3;  // d1 lacks -/+ i
+  v0 = s0 + s1;
+  v2 = s0 - s1;
+  v1 = pk_rot_add<INV>(d0, d1);
+  v3 = pk_rot_sub<INV>(d0, d1);
+}
+
 // twiddle exp(-/+ 2 pi i * idx / N) from the forward table
 template <bool INV>
 __device__ __forceinline__ c32 tw_get(const c32* __restrict__ tw, int idx) {
@@ -114,6 +198,10 @@ struct FftTwTable {
   template <int N, int LS, int R, bool INV>
   __device__ __forceinline__ c32 get(int k, int q) const {
     return tw_get<INV>(tw, k * q * (N / (LS * R)));
+  }
+  template <int N, int LS, int R>
+  __device__ __forceinline__ c32 fwd(int k, int q) const {
+    return tw[k * q * (N / (LS * R))];
   }
 };
 template <int N>
@@ -139,10 +227,15 @@ struct FftTwRegs {
     if (INV) v.im = -v.im;
     return v;
   }
+  template <int NN, int LS, int R>
+  __device__ __forceinline__ c32 fwd(int, int q) const {
+    constexpr int p = (LS == LS0) ? 0 : (LS == LS0 * 8) ? 1 : 2;
+    return w[p][q - 1];
+  }
 };
 
 template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG, bool INPLACE = false, typename SyncFn = int,
-          typename TwFn = FftTwTable>
+          typename TwFn = FftTwTable, bool PK = false>
 __device__ __forceinline__ void fft_pass_tw(c32 e[8], int t, const c32* src, c32* dst, const TwFn& twf, SyncFn sync = 0) {
   constexpr int T = N / 8;        // threads per transform
   constexpr int NB = 8 / R;       // butterflies per thread
@@ -161,16 +254,37 @@ __device__ __forceinline__ void fft_pass_tw(c32 e[8], int t, const c32* src, c32
         v[q] = src[lpad(j + q * STRIDE)];
     }
     const int k = (LS == 1) ? 0 : (j % LS);
-    if constexpr (LS > 1) {
+    if constexpr (PK) {
+      cv pv[R];
 #pragma unroll
-      for (int q = 1; q < R; q++) v[q] = cmul_f(v[q], twf.template get<N, LS, R, INV>(k, q));
-    }
-    if constexpr (R == 8) {
-      dft8<INV>(v);
-    } else if constexpr (R == 4) {
-      dft4<INV>(v[0], v[1], v[2], v[3]);
+      for (int q = 0; q < R; q++) pv[q] = cv_of(v[q]);
+      if constexpr (LS > 1) {
+#pragma unroll
+        for (int q = 1; q < R; q++) pv[q] = pk_cmul_tw<INV>(pv[q], cv_of(twf.template fwd<N, LS, R>(k, q)));
+      }
+      if constexpr (R == 8) {
+        dft8_pk<INV>(pv);
+      } else if constexpr (R == 4) {
+        dft4_pk<INV>(pv[0], pv[1], pv[2], pv[3]);
+      } else {
+        const cv sm = pv[0] + pv[1], df = pv[0] - pv[1];
+        pv[0] = sm;
+        pv[1] = df;
+      }
+#pragma unroll
+      for (int q = 0; q < R; q++) v[q] = c32_of(pv[q]);
     } else {
-      dft2(v[0], v[1]);
+      if constexpr (LS > 1) {
+#pragma unroll
+        for (int q = 1; q < R; q++) v[q] = cmul_f(v[q], twf.template get<N, LS, R, INV>(k, q));
+      }
+      if constexpr (R == 8) {
+        dft8<INV>(v);
+      } else if constexpr (R == 4) {
+        dft4<INV>(v[0], v[1], v[2], v[3]);
+      } else {
+        dft2(v[0], v[1]);
+      }
     }
     const int obase = (j - k) * R + k;  // (j / LS) * LS * R + k
     if constexpr (INPLACE) sync();
@@ -253,39 +367,39 @@ __device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __
 // The same transform (same butterflies, same twiddles, same results bit for bit) in ONE LDS buffer of
 // fft_lds_points(N) points for every N: middle passes run in place.  sync() is also called on entry, so that
 // back-to-back transforms in the same scratch are safe when the N/8 threads span more than one wave.
-template <int N, bool INV, typename SyncFn, typename TwFn>
+template <int N, bool INV, bool PK = false, typename SyncFn = int, typename TwFn = FftTwTable>
 __device__ __forceinline__ void fft_run1(c32 e[8], int t, c32* A, const TwFn& tw, SyncFn sync) {
   sync();
   if constexpr (N == 64) {
-    fft_pass_tw<64, 8, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<64, 8, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass_tw<64, 8, 8, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<64, 8, 8, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 128) {
-    fft_pass_tw<128, 2, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<128, 2, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass_tw<128, 8, 2, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
+    fft_pass_tw<128, 8, 2, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass_tw<128, 8, 16, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<128, 8, 16, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 256) {
-    fft_pass_tw<256, 4, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<256, 4, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass_tw<256, 8, 4, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
+    fft_pass_tw<256, 8, 4, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass_tw<256, 8, 32, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<256, 8, 32, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 512) {
-    fft_pass_tw<512, 8, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<512, 8, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass_tw<512, 8, 8, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
+    fft_pass_tw<512, 8, 8, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass_tw<512, 8, 64, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<512, 8, 64, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 1024) {
-    fft_pass_tw<1024, 2, 1, INV, true, false, false, SyncFn, TwFn>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<1024, 2, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass_tw<1024, 8, 2, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
+    fft_pass_tw<1024, 8, 2, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass_tw<1024, 8, 16, INV, false, false, true, SyncFn, TwFn>(e, t, A, A, tw, sync);
+    fft_pass_tw<1024, 8, 16, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass_tw<1024, 8, 128, INV, false, true, false, SyncFn, TwFn>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<1024, 8, 128, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else {
     static_assert(N <= 1024, "fft_run1 is built for the channel filter's lengths; fft_run handles N >= 2048 in one buffer");
   }

@@ -120,8 +120,14 @@ struct FilterParams {
   const c32* twF;  // [F] exp(-2 pi i k / F)
 };
 
+#ifndef FILTER_W
+#define FILTER_W 4
+#endif
+#ifndef FILTER_PK
+#define FILTER_PK true  // hand-packed butterflies (fft.h): the transform is all this kernel does
+#endif
 template <int F>
-__global__ void __launch_bounds__(256, 3) k_chan_filter(FilterParams p) {
+__global__ void __launch_bounds__(256, FILTER_W) k_chan_filter(FilterParams p) {
   constexpr int TF = F / 8;     // threads per block of the filter
   constexpr int BPR = 256 / TF; // blocks per round of a workgroup
   extern __shared__ __align__(16) unsigned char smem[];
@@ -155,17 +161,17 @@ __global__ void __launch_bounds__(256, 3) k_chan_filter(FilterParams p) {
     int tt = t;
     asm volatile("" : "+v"(tt));
     if constexpr (TF <= WAVE) {
-      fft_run1<F, false>(e, tt, sc, twr, FftWaveSync());
+      fft_run1<F, false, FILTER_PK>(e, tt, sc, twr, FftWaveSync());
     } else {
-      fft_run1<F, false>(e, tt, sc, twr, FftBlockSync());
+      fft_run1<F, false, FILTER_PK>(e, tt, sc, twr, FftBlockSync());
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) e[m] = cmul(e[m], Hr[m]);  // volk_32fc_x2_multiply_32fc
     asm volatile("" : "+v"(tt));
     if constexpr (TF <= WAVE) {
-      fft_run1<F, true>(e, tt, sc, twr, FftWaveSync());
+      fft_run1<F, true, FILTER_PK>(e, tt, sc, twr, FftWaveSync());
     } else {
-      fft_run1<F, true>(e, tt, sc, twr, FftBlockSync());
+      fft_run1<F, true, FILTER_PK>(e, tt, sc, twr, FftBlockSync());
     }
     const int64_t bs = (int64_t)((r * BPR + (uint64_t)g) * (uint64_t)B) - p.goff;  // first output of the block
 #pragma unroll
