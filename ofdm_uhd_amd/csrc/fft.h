@@ -298,69 +298,69 @@ __device__ __forceinline__ void fft_pass_tw(c32 e[8], int t, const c32* src, c32
   }
 }
 
-template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG, bool INPLACE = false, typename SyncFn = int>
+template <int N, int R, int LS, bool INV, bool FROM_REG, bool TO_REG, bool INPLACE = false, typename SyncFn = int, bool PK = false>
 __device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* dst, const c32* __restrict__ tw,
                                          SyncFn sync = 0) {
-  fft_pass_tw<N, R, LS, INV, FROM_REG, TO_REG, INPLACE, SyncFn, FftTwTable>(e, t, src, dst, FftTwTable{tw}, sync);
+  fft_pass_tw<N, R, LS, INV, FROM_REG, TO_REG, INPLACE, SyncFn, FftTwTable, PK>(e, t, src, dst, FftTwTable{tw}, sync);
 }
 
 // Full transform.  e[m] holds x[t + m*N/8] on entry and X[t + m*N/8] on exit.
 // `lds` points at this transform's 2*fft_lds_points(N) c32 scratch.  SYNC() must
 // synchronise the N/8 threads of the transform (block barrier, or nothing but a
 // compiler fence when they are one wave).
-template <int N, bool INV, typename SyncFn>
+template <int N, bool INV, typename SyncFn, bool PK = false>
 __device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __restrict__ tw, SyncFn sync) {
   c32* A = lds;
   c32* B = lds + fft_lds_points(N);
   if constexpr (N == 64) {
-    fft_pass<64, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass<64, 8, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<64, 8, 8, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass<64, 8, 8, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 128) {
-    fft_pass<128, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass<128, 2, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<128, 8, 2, INV, false, false>(e, t, A, B, tw);
+    fft_pass<128, 8, 2, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<128, 8, 16, INV, false, true>(e, t, B, nullptr, tw);
+    fft_pass<128, 8, 16, INV, false, true, false, SyncFn, PK>(e, t, B, nullptr, tw, sync);
   } else if constexpr (N == 256) {
-    fft_pass<256, 4, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass<256, 4, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<256, 8, 4, INV, false, false>(e, t, A, B, tw);
+    fft_pass<256, 8, 4, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<256, 8, 32, INV, false, true>(e, t, B, nullptr, tw);
+    fft_pass<256, 8, 32, INV, false, true, false, SyncFn, PK>(e, t, B, nullptr, tw, sync);
   } else if constexpr (N == 512) {
-    fft_pass<512, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass<512, 8, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<512, 8, 8, INV, false, false>(e, t, A, B, tw);
+    fft_pass<512, 8, 8, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<512, 8, 64, INV, false, true>(e, t, B, nullptr, tw);
+    fft_pass<512, 8, 64, INV, false, true, false, SyncFn, PK>(e, t, B, nullptr, tw, sync);
   } else if constexpr (N == 1024) {
-    fft_pass<1024, 2, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass<1024, 2, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<1024, 8, 2, INV, false, false>(e, t, A, B, tw);
+    fft_pass<1024, 8, 2, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<1024, 8, 16, INV, false, false>(e, t, B, A, tw);
+    fft_pass<1024, 8, 16, INV, false, false, false, SyncFn, PK>(e, t, B, A, tw, sync);
     sync();
-    fft_pass<1024, 8, 128, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass<1024, 8, 128, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 2048) {  // one buffer
     (void)B;
-    fft_pass<2048, 4, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass<2048, 4, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<2048, 8, 4, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass<2048, 8, 4, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<2048, 8, 32, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass<2048, 8, 32, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<2048, 8, 256, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass<2048, 8, 256, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
   } else {  // one buffer
     static_assert(N == 4096, "unsupported FFT length");
     (void)B;
-    fft_pass<4096, 8, 1, INV, true, false>(e, t, nullptr, A, tw);
+    fft_pass<4096, 8, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<4096, 8, 8, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass<4096, 8, 8, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<4096, 8, 64, INV, false, false, true>(e, t, A, A, tw, sync);
+    fft_pass<4096, 8, 64, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<4096, 8, 512, INV, false, true>(e, t, A, nullptr, tw);
+    fft_pass<4096, 8, 512, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
   }
 }
 

@@ -17,6 +17,9 @@
 #pragma once
 #include "common.h"
 #include "fft.h"
+#ifndef DEMOD_PK
+#define DEMOD_PK false  // hand-packed butterflies (fft.h)
+#endif
 #include "host_util.h"
 
 #define RAW_SLOT 4096  // bytes of frame-sink message storage per frame (MAX_PKT_LEN)
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
         for (int m = 0; m < 8; m++) q.tap_sampler[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = e[m];
       }
       // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
-      fft_run<N, false>(e, tl, fftbuf, q.tw, [] { __syncthreads(); });
+      fft_run<N, false, FftBlockSync, DEMOD_PK>(e, tl, fftbuf, q.tw, FftBlockSync());
       __syncthreads();  // every thread is done reading the FFT buffers before Ysh (= buffer A) is overwritten
 #pragma unroll
       for (int m = 0; m < 8; m++) Ysh[(tl + m * T + N / 2) & (N - 1)] = e[m];

@@ -18,6 +18,9 @@
 #pragma once
 #include "common.h"
 #include "fft.h"
+#ifndef SENSE_PK
+#define SENSE_PK false  // hand-packed butterflies (fft.h)
+#endif
 
 struct SenseParams {
   const c32* x;        // IQ stream
@@ -78,9 +81,9 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
       for (int m = 0; m < 8; m++) nx[m] = ln ? src[t + m * TPT] : mk(0.f, 0.f);
     }
     if constexpr (TPT <= WAVE) {
-      fft_run<NS, false>(e, t, my, p.tw, FftWaveSync());
+      fft_run<NS, false, FftWaveSync, SENSE_PK>(e, t, my, p.tw, FftWaveSync());
     } else {
-      fft_run<NS, false>(e, t, my, p.tw, FftBlockSync());
+      fft_run<NS, false, FftBlockSync, SENSE_PK>(e, t, my, p.tw, FftBlockSync());
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) {

@@ -9,6 +9,9 @@
 #pragma once
 #include "common.h"
 #include "fft.h"
+#ifndef TX_PK
+#define TX_PK false  // hand-packed butterflies (fft.h)
+#endif
 
 struct TxParams {
   int N, CP, L, occ, nc, nbits, arity, zl;
@@ -277,9 +280,9 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
 
   // up to N = 512 a symbol's N/8 threads sit inside one wave: no workgroup barrier in the exchanges
   if constexpr (T <= WAVE) {
-    fft_run<N, true>(e, t, lds, p.tw, FftWaveSync());
+    fft_run<N, true, FftWaveSync, TX_PK>(e, t, lds, p.tw, FftWaveSync());
   } else {
-    fft_run<N, true>(e, t, lds, p.tw, FftBlockSync());
+    fft_run<N, true, FftBlockSync, TX_PK>(e, t, lds, p.tw, FftBlockSync());
   }
 
   if (!active) return;
