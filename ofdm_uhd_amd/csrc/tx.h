@@ -238,40 +238,66 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
     s = (uint32_t)(sym - sym_off[pkt]);
   }
 
+  // ---- digital_ofdm_mapper_bcv::work for this symbol ---------------------------------------------------------
+  // The symbol's slice of the framed packet (nc * nbits bits) is fetched once, as aligned dwords, into the LDS the
+  // transform will use later, and the constellation sits in LDS too: each point then costs two LDS reads instead of
+  // a chain of three dependent global loads.
+  c32* cst = reinterpret_cast<c32*>(smem_raw) + SPW * (fft_lds_bufs(N) * fft_lds_points(N));  // [arity], shared by the workgroup
+  for (int i = threadIdx.x; i < p.arity; i += TxGeom<N>::WG) cst[i] = p.constellation[i];
+  uint32_t* mbytes = reinterpret_cast<uint32_t*>(lds);  // this symbol's message bytes (<= N + 8 of them)
+  const uint32_t nb = (uint32_t)p.nbits, bmask = (1u << nb) - 1u;
+  const uint8_t* msg = framed + framed_off[pkt];
+  const uint32_t mlen = (uint32_t)(framed_off[pkt + 1] - framed_off[pkt]);
+  const uint32_t msgbits = 8u * mlen;  // (bit positions fit 32 bits: a packet holds at most 4 105 bytes)
+  const uint32_t bit0 = (s == 0) ? 0u : (s - 1) * (uint32_t)p.nc * nb;  // first message bit of this symbol (may pass the end)
+  const uint32_t byte0 = bit0 >> 3;
+  uint32_t sh = 0;  // the chunk's first byte sits at byte `sh` of mbytes
+  if (s != 0 && byte0 < mlen) {
+    uint32_t bend = ((bit0 + (uint32_t)p.nc * nb + 7u) >> 3) + 1u;  // one byte past the last chunk's straddle
+    if (bend > mlen) bend = mlen;
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(msg + byte0);
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
+    sh = (uint32_t)(a0 & 3u);
+    const uint32_t ndw = (sh + (bend - byte0) + 3u) >> 2;
+    for (uint32_t d = (uint32_t)t; d < ndw; d += T) mbytes[d] = base[d];
+  }
+  __syncthreads();  // (the constellation is shared by the workgroup's symbols)
   c32 e[8];
   if (s == 0) {
     // ofdm_insert_preamble: the known symbol goes out ahead of the packet's first symbol
 #pragma unroll
     for (int m = 0; m < 8; m++) e[m] = p.preamble[(t + m * T + N / 2) & (N - 1)];
   } else {
-    const uint8_t* msg = framed + framed_off[pkt];
-    const uint32_t mlen = (uint32_t)(framed_off[pkt + 1] - framed_off[pkt]);
-    // bit positions fit 32 bits: a packet holds at most 4 105 bytes
-    const uint32_t msgbits = 8u * mlen;
-    const uint32_t nb = (uint32_t)p.nbits, bmask = (1u << nb) - 1u;
-    const uint32_t bit0 = (s - 1) * (uint32_t)p.nc * nb;  // first message bit of this symbol (may pass the end)
+    int car[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) car[m] = p.bin2car[(t + m * T + N / 2) & (N - 1)];  // ifftshift folded into the index
+    const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(mbytes);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
-      const int k = (t + m * T + N / 2) & (N - 1);  // ifftshift folded into the index
-      const int car = p.bin2car[k];
       c32 v = mk(0.0f, 0.0f);
-      if (car >= 0) {
-        const uint32_t b0 = bit0 + (uint32_t)car * nb;
+      if (car[m] >= 0) {
+        const uint32_t b0 = bit0 + (uint32_t)car[m] * nb;
         uint32_t bits;
         if (bit0 <= msgbits && b0 + nb <= msgbits) {
           // LSB-first bit stream cut into nbits chunks (digital_ofdm_mapper_bcv::work)
-          const uint32_t byte = b0 >> 3;
-          uint32_t w = msg[byte];
-          if (byte + 1 < mlen) w |= (uint32_t)msg[byte + 1] << 8;
+          const uint32_t byte = b0 >> 3, li = sh + (byte - byte0);
+          uint32_t w = mb8[li];
+          if (byte + 1 < mlen) w |= (uint32_t)mb8[li + 1] << 8;
           bits = (w >> (b0 & 7)) & bmask;
         } else {
-          const uint64_t slot = (uint64_t)(s - 1) * (uint64_t)p.nc + (uint64_t)car;
+          const uint64_t slot = (uint64_t)(s - 1) * (uint64_t)p.nc + (uint64_t)car[m];
           bits = pad_symbol_hash(p.pad_seed, pkt, slot, (uint32_t)p.arity);  // rand() % arity stand-in
         }
-        v = p.constellation[bits];
+        v = cst[bits];
       }
       e[m] = v;
     }
+  }
+  // the symbol's threads are done with its message bytes: the transform may use the LDS
+  if constexpr (T <= WAVE) {
+    FftWaveSync()();
+  } else {
+    __syncthreads();
   }
   if (freq_tap && active) {
 #pragma unroll
