@@ -206,13 +206,13 @@ __host__ __device__ inline SyncLds sync_lds_layout(int R, int HM) {
 struct ExactLds {
   size_t me, ue, misc, total;
 };
-__host__ __device__ inline ExactLds exact_lds_layout(int CP) {
+__host__ __device__ inline ExactLds exact_lds_layout(int CP, int rmax) {  // rmax: longest range handled
   ExactLds l;
   size_t o = 0;
   l.me = o;
-  o += ((size_t)(SYNC_TILE + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
+  o += ((size_t)(rmax + CP + 8) * sizeof(float) + 15) & ~(size_t)15;
   l.ue = o;
-  o += ((size_t)(SYNC_TILE + 8) * sizeof(float) + 15) & ~(size_t)15;
+  o += ((size_t)(rmax + 8) * sizeof(float) + 15) & ~(size_t)15;
   l.misc = o;
   o += 512;
   l.total = o;
@@ -320,6 +320,7 @@ struct Q3 {
 
 // exclusive block scan of three int64 plus block sum of three more: one barrier pair.
 // scratch: 4 waves x 6 int64 (rare path: plain shuffles)
+template <int NT>
 __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scratch, Q3* excl, Q3* sum) {
   const int lane = lane_id(), w = wave_id();
   Q3 inc = v, rs = s;
@@ -349,7 +350,7 @@ __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scra
   __syncthreads();
   Q3 base = {0, 0, 0}, sm = {0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
+  for (int i = 0; i < NT / WAVE; i++) {
     if (i < w) {
       base.pr += scratch[i * 6 + 0];
       base.pi += scratch[i * 6 + 1];
@@ -374,6 +375,7 @@ __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scra
 // Rare path (only where the float32 pre-selection found something): kept out of line so that it
 // does not weigh on the register allocation of the streaming loop.
 // ---------------------------------------------------------------------------------
+template <int NT>
 __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, float* me, float* ue, c32* gP, float* gU, long long* sc_i64,
                                                  int amin, int bmax, int D, int CP, int64_t t0s, int64_t qvalid, int64_t mvalid,
                                                  float tapcp) {
@@ -397,14 +399,14 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
   const int len = bmax - amin + 1;
   // (i) exact window sums at the anchor
   Q3 an = {0, 0, 0};
-  for (int m = s0 - D + 1 + tid; m <= s0; m += SYNC_THREADS) {
+  for (int m = s0 - D + 1 + tid; m <= s0; m += NT) {
     const Q3 q = QTERM(m);
     an.pr += q.pr;
     an.pi += q.pi;
     an.r += q.r;
   }
   // (ii) per-thread chunk of the delta sequence, scan, exact M
-  const int lc = (n_e + SYNC_THREADS - 1) / SYNC_THREADS;
+  const int lc = (n_e + NT - 1) / NT;
   const int k0 = tid * lc, k1 = (k0 + lc < n_e) ? (k0 + lc) : n_e;
   Q3 tq = {0, 0, 0};
   for (int k = k0; k < k1; k++) {
@@ -415,7 +417,7 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
     tq.r += a.r - b.r;
   }
   Q3 ex, ansum;
-  block_scan3_sum3_i64(tq, an, sc_i64, &ex, &ansum);
+  block_scan3_sum3_i64<NT>(tq, an, sc_i64, &ex, &ansum);
   long long wpr = ansum.pr + ex.pr, wpi = ansum.pi + ex.pi, wr = ansum.r + ex.r;
   for (int k = k0; k < k1; k++) {
     const int m = s0 + 1 + k;
@@ -437,14 +439,14 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
   __syncthreads();
   // (iii) exact CP-length moving sum of M over [amin, bmax]; me[k] holds sample s0+1+k = amin-CP+1+k
   long long am = 0;
-  for (int k = tid; k < CP; k += SYNC_THREADS) am += q40_from_float(me[k]);  // samples amin-CP+1 .. amin
-  const int lc2 = (len + SYNC_THREADS - 1) / SYNC_THREADS;
+  for (int k = tid; k < CP; k += NT) am += q40_from_float(me[k]);  // samples amin-CP+1 .. amin
+  const int lc2 = (len + NT - 1) / NT;
   const int j0 = tid * lc2, j1 = (j0 + lc2 < len) ? (j0 + lc2) : len;
   long long tm = 0;
   for (int jj = j0; jj < j1; jj++)
     if (jj > 0) tm += q40_from_float(me[CP - 1 + jj]) - q40_from_float(me[jj - 1]);
   Q3 mv = {tm, 0, 0}, ms_ = {am, 0, 0}, mex, msum;
-  block_scan3_sum3_i64(mv, ms_, sc_i64, &mex, &msum);
+  block_scan3_sum3_i64<NT>(mv, ms_, sc_i64, &mex, &msum);
   long long wm = msum.pr + mex.pr;
   for (int jj = j0; jj < j1; jj++) {
     if (jj > 0) wm += q40_from_float(me[CP - 1 + jj]) - q40_from_float(me[jj - 1]);
@@ -812,11 +814,18 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 //      outside.  (Where the window energy drops by 50-60 dB inside a tile the float32 sums lose the small R to
 //      cancellation -- M is then large AND a few percent off, enough to move the average later tiles inherit.)
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SYNC_THREADS) k_sync_exact(SyncParams p) {
+// Two sizes of workgroup share the list: ranges of at most EXACT_SMALL samples -- a preamble's plateau: nearly all
+// of them -- are one WAVE's work (64 threads: every scan wave-local, no barrier at all, 9 KB of LDS, 17 per CU);
+// longer ones (a carrier, the metric tap's whole tiles) take a 256-thread workgroup.
+#define EXACT_SMALL 1024
+template <int NT>
+__global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int T = SYNC_TILE;
+  constexpr bool SMALL = NT == WAVE;
+  constexpr unsigned CHUNK_C = SMALL ? 2048u : (unsigned)SYNC_CHUNK_C;  // candidates per allocation chunk (>= the longest range)
   const int tl = threadIdx.x;
-  const ExactLds L = exact_lds_layout(p.CP);
+  const ExactLds L = exact_lds_layout(p.CP, SMALL ? EXACT_SMALL : T);
   float* me = reinterpret_cast<float*>(smem + L.me);
   float* ue = reinterpret_cast<float*>(smem + L.ue);
   unsigned char* misc = smem + L.misc;
@@ -834,6 +843,7 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync_exact(SyncParams p) {
     const SyncRec rec = p.recs[ri];
     const uint64_t tile = rec.tile;
     const int amin = rec.amin, bmax = rec.bmax;
+    if ((bmax - amin + 1 <= EXACT_SMALL) != SMALL) continue;  // the other launch's record
     const uint64_t t0 = tile * (uint64_t)T;
     const int64_t t0s = (int64_t)t0;
     // the segment this tile was walked in: samples before its warm-up start count as unknown (k_sync's masks)
@@ -847,10 +857,10 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync_exact(SyncParams p) {
     // ---- 7. fixed-point re-evaluation of [amin, bmax]; stored as this tile's candidate values (u, P) ----
     const int rlen = bmax - amin + 1;
     if ((uint32_t)rlen > cand_left) {
-      if (tl == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)SYNC_CHUNK_C);  // fresh chunk
+      if (tl == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)CHUNK_C);  // fresh chunk
       __syncthreads();
       cand_base = bc[0];
-      cand_left = SYNC_CHUNK_C;
+      cand_left = CHUNK_C;
       __syncthreads();
     }
     const unsigned long long cbase = cand_base;
@@ -858,14 +868,14 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync_exact(SyncParams p) {
     cand_base += (unsigned long long)rlen;
     cand_left -= (uint32_t)rlen;
     if (fits) {
-      sync_exact_range(p.y, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, t0s, qvalid, mvalid, p.tapcp);
+      sync_exact_range<NT>(p.y, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, t0s, qvalid, mvalid, p.tapcp);
     } else {
-      for (int i = tl; i < rlen; i += SYNC_THREADS) ue[i] = -1.0f;  // nothing can be stored: no candidates
+      for (int i = tl; i < rlen; i += NT) ue[i] = -1.0f;  // nothing can be stored: no candidates
       __syncthreads();
     }
 
     // ---- 8. pieces and summary: each thread walks lc consecutive samples of the range ----
-    const int lc = (rlen + SYNC_THREADS - 1) / SYNC_THREADS;
+    const int lc = (rlen + NT - 1) / NT;
     const int j0 = tl * lc, j1 = (j0 + lc < rlen) ? (j0 + lc) : rlen;
     Aff f;
     f.A = 1.0;
@@ -899,7 +909,7 @@ __global__ void __launch_bounds__(SYNC_THREADS) k_sync_exact(SyncParams p) {
     pre.b = tot.b = 0.0;
     {
       const int w = wave_id();
-      for (int i = 0; i < SYNC_THREADS / WAVE; i++) {
+      for (int i = 0; i < NT / WAVE; i++) {
         Aff g;
         g.A = sc_f64[2 * i];
         g.b = sc_f64[2 * i + 1];
