@@ -279,6 +279,12 @@ int ofdm_sense_redecide(ofdm_handle *h, const ofdm_sense_cfg *sc);
  *    block length counted from the first sample the flow graph ever saw; the engine lays its filter blocks on
  *    that same grid, so a capture handed over in pieces is filtered exactly as one call would filter it. */
 int ofdm_rx_set_origin(ofdm_handle *h, uint64_t first_sample_index);
+/* Pipelining across batches (one handle = a transmit stream and a receive stream on the GPU): ofdm_rx_submit queues
+ * the receiver's input stage (the wait for the transmit batch that fills iq, the channel filter) and returns at
+ * once; an ofdm_tx_async issued next is queued behind that stage only -- it may refill the same iq buffer -- and runs
+ * while the following ofdm_rx(h, iq, nsamples, ...) (same arguments: it picks the submitted stage up) is busy with
+ * its own kernels and host round trips.  Optional: ofdm_rx alone does the same work in order. */
+int ofdm_rx_submit(ofdm_handle *h, const ofdm_c32 *iq, uint64_t nsamples);
 int ofdm_rx_packet_pos(ofdm_handle *h, uint64_t *pos, int cap, int *n);
 int ofdm_rx_nco_state(ofdm_handle *h, uint64_t *flags, uint64_t *phase, double *step, uint8_t *swallowed,
                       int cap, int *n);

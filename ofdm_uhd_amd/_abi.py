@@ -112,7 +112,7 @@ EXPORTS = (
     "ofdm_set_taps", "ofdm_tap", "ofdm_prof_enable", "ofdm_prof_reset", "ofdm_prof_get",
     "ofdm_kernel_name", "ofdm_sense_count", "ofdm_sense", "ofdm_sense_decide", "ofdm_set_rx_sense",
     "ofdm_rx_sense_result", "ofdm_sense_device_msgs", "ofdm_sense_redecide",
-    "ofdm_rx_packet_pos", "ofdm_rx_nco_state", "ofdm_rx_set_flag_history", "ofdm_rx_set_origin",
+    "ofdm_rx_packet_pos", "ofdm_rx_nco_state", "ofdm_rx_set_flag_history", "ofdm_rx_set_origin", "ofdm_rx_submit",
 )
 
 _LIB = None
@@ -160,6 +160,7 @@ def _declare(lib):
     lib.ofdm_rx_packet_pos.argtypes = [H, vp, C.c_int, C.POINTER(C.c_int)]
     lib.ofdm_rx_nco_state.argtypes = [H, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.ofdm_rx_set_origin.argtypes = [H, C.c_uint64]
+    lib.ofdm_rx_submit.argtypes = [H, C.c_void_p, C.c_uint64]
     lib.ofdm_rx_set_flag_history.argtypes = [H, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, C.c_uint64, C.c_double]
     lib.ofdm_sense_device_msgs.argtypes = [H, C.POINTER(C.c_void_p), u64p, u32p]
     lib.ofdm_sense_redecide.argtypes = [H, SC]

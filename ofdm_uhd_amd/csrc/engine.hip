@@ -54,6 +54,14 @@ struct ofdm_handle {
   int nmap = 0;  // data carriers of the frame sink (map into the occupied block)
   bool dev_ptrs = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  // The transmit side runs on a stream of its own (txs) so that a caller may queue the next batch's modulation
+  // behind the receiver's input stage (ofdm_rx_submit) and let it fill the receiver's host round trips:
+  //   ev_tx_done  end of the last queued transmit batch      -> the receiver's stream waits for it
+  //   ev_rx_in    the receiver has consumed its input buffer  -> the next transmit batch waits for it
+  //   ev_tx_staged  the last batch's metadata left the pinned staging buffer
+  hipStream_t own_txs = nullptr, txs = nullptr;
+  hipEvent_t ev_tx_done = nullptr, ev_rx_in = nullptr, ev_tx_staged = nullptr;
+  bool tx_pending = false, rx_in_pending = false, tx_staged_pending = false;
   std::string err;
 
   // constant tables
@@ -236,6 +244,7 @@ static int apply_carrier_map(ofdm_handle* h, const char* hex) {
   std::vector<int16_t> smap16(smap.begin(), smap.end());
   // work in flight may still read the old tables
   if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->txs) HIPCHK(h, hipStreamSynchronize(h->txs));
   HIPCHK(h, upload(h->d_bin2car, bin2car.data(), bin2car.size()));
   HIPCHK(h, upload(h->d_smap, smap16.data(), smap16.size()));
   h->nc = (int)cmap.size();
@@ -273,6 +282,11 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   HIPCHK(h, hipSetDevice(cfg->device_id));
   HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
+  HIPCHK(h, hipStreamCreateWithFlags(&h->own_txs, hipStreamNonBlocking));
+  h->txs = h->own_txs;
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_tx_done, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx_in, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_tx_staged, hipEventDisableTiming));
 
   h->cfg.carrier_map[OFDM_MAX_CARRIER_HEX + 7] = 0;
   {
@@ -377,6 +391,7 @@ extern "C" int ofdm_create(const ofdm_cfg* cfg, ofdm_handle** out) {
 extern "C" void ofdm_destroy(ofdm_handle* h) {
   if (!h) return;
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+  if (h->own_txs) (void)hipStreamSynchronize(h->own_txs);
   DevBuf* bufs[] = {&h->d_const,    &h->d_preamble,    &h->d_tw,          &h->d_bin2car, &h->d_mask,
                     &h->d_crc,      &h->d_Hf,   &h->d_twF,     &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
                     &h->d_payloads, &h->d_payload_off, &h->d_payload_len, &h->d_framed,  &h->d_framed_off,
@@ -394,13 +409,19 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
     if (ss.side) (void)hipStreamDestroy(ss.side);
   }
   h->prof.destroy();
+  if (h->ev_tx_done) (void)hipEventDestroy(h->ev_tx_done);
+  if (h->ev_rx_in) (void)hipEventDestroy(h->ev_rx_in);
+  if (h->ev_tx_staged) (void)hipEventDestroy(h->ev_tx_staged);
+  if (h->own_txs) (void)hipStreamDestroy(h->own_txs);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
 
 extern "C" int ofdm_set_stream(ofdm_handle* h, void* s) {
   if (!h) return OFDM_E_INVAL;
+  // a caller-owned stream carries both sides (everything in the caller's order); NULL: the handle's own two
   h->stream = s ? (hipStream_t)s : h->own_stream;
+  h->txs = s ? (hipStream_t)s : h->own_txs;
   return OFDM_OK;
 }
 
@@ -509,6 +530,10 @@ static int stage_batch(ofdm_handle* h, const uint8_t* payloads, const uint64_t* 
   const size_t n1 = (size_t)npkt + 1;
   // pinned staging: payload_off[npkt] | framed_off[n1] | sym_off[n1] | payload_len[npkt]
   size_t bytes = sizeof(uint64_t) * (npkt + 2 * n1) + sizeof(uint32_t) * npkt;
+  if (h->tx_staged_pending) {  // the previous batch's copies out of the pinned staging buffer must be done
+    HIPCHK(h, hipEventSynchronize(h->ev_tx_staged));
+    h->tx_staged_pending = false;
+  }
   HIPCHK(h, h->h_meta.ensure(bytes));
   uint64_t* m_poff = h->h_meta.as<uint64_t>();
   uint64_t* m_foff = m_poff + npkt;
@@ -522,17 +547,19 @@ static int stage_batch(ofdm_handle* h, const uint8_t* payloads, const uint64_t* 
   HIPCHK(h, h->d_framed_off.ensure(sizeof(uint64_t) * n1));
   HIPCHK(h, h->d_sym_off.ensure(sizeof(uint64_t) * n1));
   HIPCHK(h, h->d_payload_len.ensure(sizeof(uint32_t) * n1));
-  HIPCHK(h, hipMemcpyAsync(h->d_payload_off.p, m_poff, sizeof(uint64_t) * npkt, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_framed_off.p, m_foff, sizeof(uint64_t) * n1, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_sym_off.p, m_soff, sizeof(uint64_t) * n1, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_payload_len.p, m_plen, sizeof(uint32_t) * npkt, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_payload_off.p, m_poff, sizeof(uint64_t) * npkt, hipMemcpyHostToDevice, h->txs));
+  HIPCHK(h, hipMemcpyAsync(h->d_framed_off.p, m_foff, sizeof(uint64_t) * n1, hipMemcpyHostToDevice, h->txs));
+  HIPCHK(h, hipMemcpyAsync(h->d_sym_off.p, m_soff, sizeof(uint64_t) * n1, hipMemcpyHostToDevice, h->txs));
+  HIPCHK(h, hipMemcpyAsync(h->d_payload_len.p, m_plen, sizeof(uint32_t) * npkt, hipMemcpyHostToDevice, h->txs));
+  HIPCHK(h, hipEventRecord(h->ev_tx_staged, h->txs));
+  h->tx_staged_pending = true;
   if (h->dev_ptrs) {
     *d_payloads = payloads;
   } else {
     uint64_t total = 0;
     for (int k = 0; k < npkt; k++) total = std::max<uint64_t>(total, payload_off[k] + payload_len[k]);
     HIPCHK(h, h->d_payloads.ensure(std::max<uint64_t>(total, 1)));
-    if (total) HIPCHK(h, hipMemcpyAsync(h->d_payloads.p, payloads, total, hipMemcpyHostToDevice, h->stream));
+    if (total) HIPCHK(h, hipMemcpyAsync(h->d_payloads.p, payloads, total, hipMemcpyHostToDevice, h->txs));
     *d_payloads = h->d_payloads.as<uint8_t>();
   }
   return OFDM_OK;
@@ -540,11 +567,11 @@ static int stage_batch(ofdm_handle* h, const uint8_t* payloads, const uint64_t* 
 
 static int launch_frame_pack(ofdm_handle* h, const uint8_t* d_payloads, int npkt, uint8_t* d_framed) {
   TxParams p = make_tx_params(h);
-  h->prof.begin(OFDM_K_FRAME, h->stream);
-  hipLaunchKernelGGL(k_frame_pack, dim3((npkt + 3) / 4), dim3(256), 0, h->stream, p, d_payloads,
+  h->prof.begin(OFDM_K_FRAME, h->txs);
+  hipLaunchKernelGGL(k_frame_pack, dim3((npkt + 3) / 4), dim3(256), 0, h->txs, p, d_payloads,
                      h->d_payload_off.as<uint64_t>(), h->d_payload_len.as<uint32_t>(), h->d_framed_off.as<uint64_t>(),
                      npkt, d_framed, h->d_xp8.as<uint32_t>());
-  h->prof.end(h->stream);
+  h->prof.end(h->txs);
   HIPCHK(h, hipGetLastError());
   return OFDM_OK;
 }
@@ -573,8 +600,8 @@ extern "C" int ofdm_make_packets(ofdm_handle* h, const uint8_t* payloads, const 
   }
   rc = launch_frame_pack(h, d_payloads, npkt, d_framed);
   if (rc) return rc;
-  if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(framed, d_framed, total, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(framed, d_framed, total, hipMemcpyDeviceToHost, h->txs));
+  HIPCHK(h, hipStreamSynchronize(h->txs));
   h->prof.collect();
   return OFDM_OK;
 }
@@ -585,18 +612,18 @@ static void launch_tx_mod(ofdm_handle* h, const TxParams& p, const uint8_t* d_fr
   constexpr int SPW = TxGeom<N>::SPW, WG = TxGeom<N>::WG;
   const size_t shmem = (size_t)SPW * fft_lds_bytes(N) + OFDM_MAX_ARITY * sizeof(c32);  // transforms' buffers | constellation
   const unsigned grid = (unsigned)((nsym + SPW - 1) / SPW);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N>), dim3(grid), dim3(WG), shmem, h->stream, p, d_framed,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N>), dim3(grid), dim3(WG), shmem, h->txs, p, d_framed,
                      h->d_framed_off.as<uint64_t>(), h->d_sym_off.as<uint64_t>(), h->d_sym_pkt.as<uint32_t>(),
                      uniform_spp, nsym, lead, d_out, d_freq_tap, d_ifft_tap);
 }
 
-static int launch_noise(ofdm_handle* h, c32* d_iq, uint64_t n, uint64_t index0, int zero_input, const ofdm_chan& ch) {
+static int launch_noise(ofdm_handle* h, hipStream_t st, c32* d_iq, uint64_t n, uint64_t index0, int zero_input, const ofdm_chan& ch) {
   if (n == 0) return OFDM_OK;
   const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 8);
-  h->prof.begin(OFDM_K_CHAN, h->stream);
-  hipLaunchKernelGGL(k_channel, dim3(grid), dim3(256), 0, h->stream, d_iq, n, index0, zero_input, ch.sigma, ch.cfo,
+  h->prof.begin(OFDM_K_CHAN, st);
+  hipLaunchKernelGGL(k_channel, dim3(grid), dim3(256), 0, st, d_iq, n, index0, zero_input, ch.sigma, ch.cfo,
                      ch.seed, ch.stream_id);
-  h->prof.end(h->stream);
+  h->prof.end(st);
   HIPCHK(h, hipGetLastError());
   return OFDM_OK;
 }
@@ -624,6 +651,8 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
   if (total == 0) return OFDM_OK;
   if (!iq_out) FAIL(h, OFDM_E_INVAL, "null iq_out");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  // the receiver may still be reading the buffer this batch writes (ofdm_rx_submit / ofdm_rx in flight)
+  if (h->rx_in_pending && h->txs != h->stream) HIPCHK(h, hipStreamWaitEvent(h->txs, h->ev_rx_in, 0));
 
   c32* d_out = reinterpret_cast<c32*>(iq_out);
   if (!h->dev_ptrs) {
@@ -639,7 +668,7 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
     if (rc) return rc;
     HIPCHK(h, h->d_sym_pkt.ensure(sizeof(uint32_t) * std::max<uint64_t>(nsym, 1)));
     if (!uni) {
-      hipLaunchKernelGGL(k_sym_desc, dim3((npkt + 255) / 256), dim3(256), 0, h->stream, h->d_sym_off.as<uint64_t>(), npkt,
+      hipLaunchKernelGGL(k_sym_desc, dim3((npkt + 255) / 256), dim3(256), 0, h->txs, h->d_sym_off.as<uint64_t>(), npkt,
                          h->d_sym_pkt.as<uint32_t>());
       HIPCHK(h, hipGetLastError());
     }
@@ -654,7 +683,7 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
     }
     TxParams p = make_tx_params(h);
     const uint32_t uspp = uni ? spp : 0;
-    h->prof.begin(OFDM_K_TX, h->stream);
+    h->prof.begin(OFDM_K_TX, h->txs);
     switch (h->N) {
       case 64: launch_tx_mod<64>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
       case 128: launch_tx_mod<128>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
@@ -664,7 +693,7 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
       case 2048: launch_tx_mod<2048>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
       default: launch_tx_mod<4096>(h, p, h->d_framed.as<uint8_t>(), uspp, nsym, lead, d_out, d_freq, d_ifft); break;
     }
-    h->prof.end(h->stream);
+    h->prof.end(h->txs);
     HIPCHK(h, hipGetLastError());
   }
   h->last_tx_nsym = nsym;
@@ -673,19 +702,23 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
   h->last_tx_framed_bytes = npkt ? h->framed_off[npkt] : 0;
   // noise-only lead-in and tail (the modulator covers everything in between)
   if (h->chan_on) {
-    rc = launch_noise(h, d_out, lead, 0, 1, h->chan);
+    rc = launch_noise(h, h->txs, d_out, lead, 0, 1, h->chan);
     if (rc) return rc;
-    rc = launch_noise(h, d_out + lead + nsym * (uint64_t)h->L, tail, lead + nsym * (uint64_t)h->L, 1, h->chan);
+    rc = launch_noise(h, h->txs, d_out + lead + nsym * (uint64_t)h->L, tail, lead + nsym * (uint64_t)h->L, 1, h->chan);
     if (rc) return rc;
   }
-  if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(iq_out, d_out, total * sizeof(c32), hipMemcpyDeviceToHost, h->stream));
+  if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(iq_out, d_out, total * sizeof(c32), hipMemcpyDeviceToHost, h->txs));
+  HIPCHK(h, hipEventRecord(h->ev_tx_done, h->txs));
+  h->tx_pending = true;
   return OFDM_OK;
 }
 
 extern "C" int ofdm_wait(ofdm_handle* h) {
   if (!h) return OFDM_E_INVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->txs));
+  if (h->stream != h->txs) HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->tx_pending = false;
   h->prof.collect();
   return OFDM_OK;
 }
@@ -713,7 +746,7 @@ extern "C" int ofdm_channel(ofdm_handle* h, ofdm_c32* iq, uint64_t n, const ofdm
     d = h->d_iq_stage.as<c32>();
     HIPCHK(h, hipMemcpyAsync(d, iq, n * sizeof(c32), hipMemcpyHostToDevice, h->stream));
   }
-  int rc = launch_noise(h, d, n, index0, 0, *chan);
+  int rc = launch_noise(h, h->stream, d, n, index0, 0, *chan);
   if (rc) return rc;
   if (!h->dev_ptrs) HIPCHK(h, hipMemcpyAsync(iq, d, n * sizeof(c32), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

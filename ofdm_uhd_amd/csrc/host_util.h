@@ -61,49 +61,64 @@ struct PinBuf {
 struct ProfSpan {
   int kernel;
   hipEvent_t a, b;
+  bool busy;
 };
 
+// Per-kernel HIP-event timing.  Spans may sit on different streams (the transmit and receive sides of a handle run
+// on their own): collect() takes the spans whose end event has completed and leaves the others for a later call.
 struct Profiler {
   bool on = false;
   double total_ms[OFDM_K_COUNT] = {0};
   uint64_t launches[OFDM_K_COUNT] = {0};
   std::vector<ProfSpan> pool;  // events, reused call after call
-  size_t used = 0;
+  int open = -1;               // span begun and not yet ended
 
   void begin(int k, hipStream_t s) {
     if (!on) return;
-    if (used == pool.size()) {
+    int idx = -1;
+    for (size_t i = 0; i < pool.size(); i++)
+      if (!pool[i].busy) {
+        idx = (int)i;
+        break;
+      }
+    if (idx < 0) {
       ProfSpan sp;
       sp.kernel = k;
+      sp.busy = false;
       (void)hipEventCreate(&sp.a);
       (void)hipEventCreate(&sp.b);
       pool.push_back(sp);
+      idx = (int)pool.size() - 1;
     }
-    pool[used].kernel = k;
-    (void)hipEventRecord(pool[used].a, s);
+    pool[idx].kernel = k;
+    pool[idx].busy = true;
+    (void)hipEventRecord(pool[idx].a, s);
+    open = idx;
   }
   void end(hipStream_t s) {
-    if (!on) return;
-    (void)hipEventRecord(pool[used].b, s);
-    used++;
+    if (!on || open < 0) return;
+    (void)hipEventRecord(pool[open].b, s);
+    open = -1;
   }
-  // call after the stream has been synchronised
   void collect() {
-    for (size_t i = 0; i < used; i++) {
+    for (size_t i = 0; i < pool.size(); i++) {
+      if (!pool[i].busy || (int)i == open) continue;
+      if (hipEventQuery(pool[i].b) != hipSuccess) continue;  // still running (another stream): next time
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, pool[i].a, pool[i].b) == hipSuccess) {
         total_ms[pool[i].kernel] += (double)ms;
         launches[pool[i].kernel] += 1;
       }
+      pool[i].busy = false;
     }
-    used = 0;
   }
   void reset() {
     for (int i = 0; i < OFDM_K_COUNT; i++) {
       total_ms[i] = 0;
       launches[i] = 0;
     }
-    used = 0;
+    for (auto& sp : pool) sp.busy = false;
+    open = -1;
   }
   void destroy() {
     for (auto& sp : pool) {
@@ -111,6 +126,6 @@ struct Profiler {
       (void)hipEventDestroy(sp.b);
     }
     pool.clear();
-    used = 0;
+    open = -1;
   }
 };

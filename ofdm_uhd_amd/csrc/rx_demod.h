@@ -833,6 +833,11 @@ struct RxState {
       out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, stash_peaks, stash_P, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos, tap_sampler, tap_sigmix, tap_nco;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
   const c32* y_ptr = nullptr;  // chan_filt's output of the last call: rx.y, or the input itself (SYNC "fixed")
+  // ofdm_rx_submit: the input stage of the next ofdm_rx call is already queued for this buffer
+  bool sub_valid = false, in_event_at_end = false;
+  const void* sub_iq = nullptr;
+  uint64_t sub_n = 0;
+  const c32* sub_dx = nullptr;
   uint64_t origin = 0;  // index, in its capture, of the first sample of the ofdm_rx calls (ofdm_rx_set_origin)
   std::vector<uint64_t> last_pos;  // host copy: flag sample of every packet of the last call
   // chunked streams (ofdm_rx_set_flag_history): flags settled by earlier calls replace whatever this call

@@ -214,6 +214,13 @@ class Engine(object):
         self._check(rc)
         return [(bool(ok[i]), pay[int(off[i]):int(off[i]) + int(ln[i])].tobytes()) for i in range(npk.value)]
 
+    def rx_submit_device(self, iq_ptr, nsamples):
+        """Queue the receiver's input stage for this buffer and return at once (ofdm_rx_submit): a tx_device(...,
+        wait=False) issued next is held back only until that stage has read the buffer, and runs beside the
+        rx_device() call that follows with the same arguments."""
+        assert self.device_ptrs
+        self._check(self._lib.ofdm_rx_submit(self._h, C.c_void_p(iq_ptr), int(nsamples)))
+
     def rx_device(self, iq_ptr, nsamples, payload_ptr, payload_cap, max_pkts):
         """Device mode.  Returns (npkt, off, len, ok) with NumPy metadata arrays."""
         assert self.device_ptrs
