@@ -81,6 +81,7 @@ struct SyncParams {
   uint64_t cand_cap;
   unsigned long long* cand_count;  // device counter
   unsigned int* overflow;          // device flag
+  int exact_small;                 // k_sync_exact: ranges up to this many samples go to the wave-sized workgroups
   SyncRec* recs;                   // [ntiles]
   unsigned long long* rec_count;   // device counter
 };
@@ -814,10 +815,17 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 //      outside.  (Where the window energy drops by 50-60 dB inside a tile the float32 sums lose the small R to
 //      cancellation -- M is then large AND a few percent off, enough to move the average later tiles inherit.)
 // ---------------------------------------------------------------------------------
-// Two sizes of workgroup share the list: ranges of at most EXACT_SMALL samples -- a preamble's plateau: nearly all
-// of them -- are one WAVE's work (64 threads: every scan wave-local, no barrier at all, 9 KB of LDS, 17 per CU);
-// longer ones (a carrier, the metric tap's whole tiles) take a 256-thread workgroup.
-#define EXACT_SMALL 1024
+// Two sizes of workgroup share the list: ranges of at most p.exact_small samples -- a preamble's plateau (about CP
+// samples plus the guard band's margin): nearly all of them -- are one WAVE's work (64 threads: every scan
+// wave-local, no barrier at all, 9 KB of LDS at C2, 17 workgroups per CU); longer ones (a carrier, the metric tap's
+// whole tiles) take a 256-thread workgroup.
+// (measured: at N = 2048 / 4096 a single wave per range is 3-4x slower than the workgroup -- the window sums alone are
+//  N/2 terms per range -- so the wave-sized variant serves N <= 512 only: C2 1.15 -> 0.62 ms, C3 0.58 vs 1.5-2.4 ms)
+__host__ __device__ inline int sync_exact_small(int CP, int D) {
+  if (D > 256) return 0;
+  const int r = 2 * CP + 768;
+  return r > SYNC_TILE ? SYNC_TILE : r;
+}
 template <int NT>
 __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -825,7 +833,7 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
   constexpr bool SMALL = NT == WAVE;
   constexpr unsigned CHUNK_C = SMALL ? 2048u : (unsigned)SYNC_CHUNK_C;  // candidates per allocation chunk (>= the longest range)
   const int tl = threadIdx.x;
-  const ExactLds L = exact_lds_layout(p.CP, SMALL ? EXACT_SMALL : T);
+  const ExactLds L = exact_lds_layout(p.CP, SMALL ? p.exact_small : T);
   float* me = reinterpret_cast<float*>(smem + L.me);
   float* ue = reinterpret_cast<float*>(smem + L.ue);
   unsigned char* misc = smem + L.misc;
@@ -843,7 +851,7 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
     const SyncRec rec = p.recs[ri];
     const uint64_t tile = rec.tile;
     const int amin = rec.amin, bmax = rec.bmax;
-    if ((bmax - amin + 1 <= EXACT_SMALL) != SMALL) continue;  // the other launch's record
+    if ((bmax - amin + 1 <= p.exact_small) != SMALL) continue;  // the other launch's record
     const uint64_t t0 = tile * (uint64_t)T;
     const int64_t t0s = (int64_t)t0;
     // the segment this tile was walked in: samples before its warm-up start count as unknown (k_sync's masks)

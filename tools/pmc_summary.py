@@ -21,7 +21,7 @@ for sub in ("pmc1", "pmc2", "pmc3", "pmc4"):
             seen[k] += 1
     print("==", sub)
     for k in agg:
-        if not any(t in k for t in ("k_sync", "k_rx_demod", "k_tx_mod", "k_deframe_write", "k_frame_pack", "k_peak")):
+        if not any(t in k for t in ("k_sync", "k_rx_demod", "k_tx_mod", "k_deframe_write", "k_frame_pack", "k_peak", "k_chan_filter", "k_sense")):
             continue
         n = seen[k]
         print("  %-30s x%d " % (k, n) + " ".join("%s=%.4g" % (c.replace("SQ_", ""), v / n) for c, v in sorted(agg[k].items())))
