@@ -65,7 +65,8 @@ struct ofdm_handle {
   std::string err;
 
   // constant tables
-  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_Hf, d_twF, d_ks, d_smap, d_kd, d_xp8;
+  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_Hf, d_twF, d_ks, d_smap, d_kd, d_xp8, d_grid;
+  bool has_grid = false;  // the constellation is a full grid of levels (QAM tables): constant-time slicer
   int filtF = 0;  // transform length of the channel filter (sync_filter_F)
 
   // TX workspaces
@@ -342,6 +343,44 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
     kd[i] = dr * dr + di * di;
   }
   HIPCHK(h, upload(h->d_const, reinterpret_cast<const c32*>(cfg->constellation), cfg->arity));
+  {
+    // grid structure of the constellation (qam.py:29-73 builds every combination of its levels): distinct real and
+    // imaginary parts by exact float comparison, every pair present once
+    SlicerGrid g;
+    memset(&g, 0, sizeof(g));
+    std::vector<float> lr, li;
+    for (uint32_t i = 0; i < cfg->arity; i++) {
+      lr.push_back(cfg->constellation[i].re);
+      li.push_back(cfg->constellation[i].im);
+    }
+    std::sort(lr.begin(), lr.end());
+    std::sort(li.begin(), li.end());
+    lr.erase(std::unique(lr.begin(), lr.end()), lr.end());
+    li.erase(std::unique(li.begin(), li.end()), li.end());
+    bool ok = cfg->arity >= 16 && lr.size() >= 2 && li.size() >= 2 && lr.size() <= 16 && li.size() <= 16 &&
+              lr.size() * li.size() == cfg->arity;
+    if (ok) {
+      std::vector<int> seen(cfg->arity, 0);
+      float amax = 0.f;
+      for (uint32_t i = 0; i < cfg->arity && ok; i++) {
+        const float re = cfg->constellation[i].re, im = cfg->constellation[i].im;
+        if (!(re == re) || !(im == im)) ok = false;
+        const size_t a = std::lower_bound(lr.begin(), lr.end(), re) - lr.begin();
+        const size_t b = std::lower_bound(li.begin(), li.end(), im) - li.begin();
+        const size_t cell = a * li.size() + b;
+        if (seen[cell]++) ok = false;
+        g.idx[cell] = (uint8_t)i;
+        amax = fmaxf(amax, fmaxf(fabsf(re), fabsf(im)));
+      }
+      g.nr = (int)lr.size();
+      g.ni = (int)li.size();
+      g.bound = 64.0f * amax;
+      for (size_t a = 0; a < lr.size(); a++) g.lr[a] = lr[a];
+      for (size_t b = 0; b < li.size(); b++) g.li[b] = li[b];
+    }
+    h->has_grid = ok;
+    if (ok) HIPCHK(h, upload(h->d_grid, &g, (size_t)1));
+  }
   HIPCHK(h, upload(h->d_preamble, pre.data(), pre.size()));
   HIPCHK(h, upload(h->d_tw, tw.data(), tw.size()));
   HIPCHK(h, upload(h->d_mask, cfg->whitening_mask, (size_t)OFDM_MASK_LEN));
@@ -393,7 +432,7 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   if (h->own_txs) (void)hipStreamSynchronize(h->own_txs);
   DevBuf* bufs[] = {&h->d_const,    &h->d_preamble,    &h->d_tw,          &h->d_bin2car, &h->d_mask,
-                    &h->d_crc,      &h->d_Hf,   &h->d_twF,     &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
+                    &h->d_crc,      &h->d_Hf,   &h->d_twF,     &h->d_grid,    &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
                     &h->d_payloads, &h->d_payload_off, &h->d_payload_len, &h->d_framed,  &h->d_framed_off,
                     &h->d_sym_off,  &h->d_sym_pkt,     &h->d_iq_stage,    &h->d_freq_tap, &h->d_ifft_tap};
   for (DevBuf* b : bufs) b->release();

@@ -128,6 +128,15 @@ __global__ void __launch_bounds__(256) k_frames(FramesParams q) {
 }
 
 // ------------------------------------------------------------------------------------
+// A constellation whose points are every combination of nr real and ni imaginary levels (the QAM tables of
+// qam.py:29-73): the slicer then needs the two levels around each part, not a search over the whole table.
+struct SlicerGrid {
+  int nr, ni;
+  float bound;        // beyond it (garbage frames) float32 rounding could rank a far point first: full search
+  float lr[16], li[16];  // levels, ascending
+  uint8_t idx[256];   // constellation index of (real level a, imaginary level b) at a * ni + b
+};
+
 struct DemodParams {
   int N, CP, L, occ, zl, nmap, nbits, arity, shift;
   float phase_gain, freq_gain, eq_gain;
@@ -145,6 +154,7 @@ struct DemodParams {
   const float* kd;      // [occ]
   const int16_t* smap;  // [nmap]
   const c32* constellation;
+  const SlicerGrid* grid;  // nullptr: no grid structure (PSK, small tables): search the table
   const uint8_t* invalid;  // [nframes] (tap pass)
   FrameResult* res;        // [nframes]
   uint8_t* raw;            // [nframes][RAW_SLOT]
@@ -166,7 +176,7 @@ __host__ __device__ inline int demod_symbits_words(int nmap, int nbits) { return
 template <int N>
 __host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int nbits) {
   return fft_lds_bytes(N) + 2 * occ * (int)sizeof(c32) + arity * (int)sizeof(c32) + 64 * (int)sizeof(float) +
-         demod_symbits_words(nmap, nbits) * 4 + 64;
+         demod_symbits_words(nmap, nbits) * 4 + 64 + (int)sizeof(SlicerGrid);
 }
 
 // sum over the N/8 threads of the frame (two values at once)
@@ -266,6 +276,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
   float* red = reinterpret_cast<float*>(cst + q.arity);
   uint32_t* sbits = reinterpret_cast<uint32_t*>(red + 64);
   const int sbw = demod_symbits_words(q.nmap, q.nbits);
+  SlicerGrid* grid = reinterpret_cast<SlicerGrid*>(sbits + ((sbw + 3) & ~3));
+  const bool use_grid = q.grid != nullptr;
 
   const int t = threadIdx.x;
   const uint32_t f = blockIdx.x;
@@ -290,6 +302,9 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
     dfe[i] = mk(1.f, 0.f);
   }
   for (int i = t; i < q.arity; i += T) cst[i] = q.constellation[i];
+  if (use_grid)
+    for (int i = t; i < (int)(sizeof(SlicerGrid) / 4); i += T)
+      reinterpret_cast<uint32_t*>(grid)[i] = reinterpret_cast<const uint32_t*>(q.grid)[i];
   __syncthreads();
 
   uint32_t cf = f;  // frame whose symbols are being consumed
@@ -488,14 +503,35 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
         const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
         const c32 in = cmul(cmul(hinv[i], comp), Y);
         const c32 sigrot = cmul(cmul(in, carrier), dfe[c]);
-        // slicer: first minimum of |x - pos[j]|^2
+        // slicer: first minimum of |x - pos[j]|^2 over the table (digital_ofdm_frame_sink::slicer).  On a grid
+        // constellation the minimum is one of the four points whose levels bracket the two parts: those four are
+        // evaluated with the SAME float32 expression and the first (lowest-index) minimum among them is taken --
+        // the full search's answer, at 4 distance evaluations instead of `arity`.
         unsigned best = 0;
-        float bestd = cnorm(csub(sigrot, cst[0]));
-        for (int jj = 1; jj < q.arity; jj++) {
-          const float dd = cnorm(csub(sigrot, cst[jj]));
-          if (dd < bestd) {
-            bestd = dd;
-            best = (unsigned)jj;
+        float bestd;
+        if (use_grid && fabsf(sigrot.re) <= grid->bound && fabsf(sigrot.im) <= grid->bound) {
+          int ka = 0, kb = 0;
+          for (int a = 1; a < grid->nr - 1; a++) ka += (sigrot.re >= grid->lr[a]) ? 1 : 0;
+          for (int b = 1; b < grid->ni - 1; b++) kb += (sigrot.im >= grid->li[b]) ? 1 : 0;
+          best = grid->idx[ka * grid->ni + kb];
+          bestd = cnorm(csub(sigrot, cst[best]));
+#pragma unroll
+          for (int c4 = 1; c4 < 4; c4++) {
+            const unsigned cand = grid->idx[(ka + (c4 >> 1)) * grid->ni + kb + (c4 & 1)];
+            const float dd = cnorm(csub(sigrot, cst[cand]));
+            if (dd < bestd || (dd == bestd && cand < best)) {
+              bestd = dd;
+              best = cand;
+            }
+          }
+        } else {
+          bestd = cnorm(csub(sigrot, cst[0]));
+          for (int jj = 1; jj < q.arity; jj++) {
+            const float dd = cnorm(csub(sigrot, cst[jj]));
+            if (dd < bestd) {
+              bestd = dd;
+              best = (unsigned)jj;
+            }
           }
         }
         const c32 closest = cst[best];
