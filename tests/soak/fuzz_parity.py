@@ -16,7 +16,10 @@ t_end = time.time() + budget
 ncase = nbad = 0
 while time.time() < t_end:
     N = int(rng.choice([64, 128, 256, 512, 512, 512, 1024, 2048, 4096]))
-    occ = int(rng.integers(4, N // 4 - 1)) * 4 if N > 64 else int(rng.choice([16, 32, 48, 60]))
+    # multiples of 4 and, now and then, of 2: partial-nibble carrier maps (mapper and sink index rules differ)
+    occ = int(rng.integers(4, N // 4 - 1)) * 4 if N > 64 else int(rng.choice([16, 32, 48, 52, 60]))
+    if rng.random() < 0.15:
+        occ += 2
     occ = max(16, min(occ, N - 4))
     CP = int(rng.integers(1, max(2, N // 2)))
     if rng.random() < 0.5:
@@ -69,7 +72,7 @@ while time.time() < t_end:
         eng.set_taps(_abi.TAP_TX_FREQ)
         iq_g = eng.tx(pay)
         assert np.array_equal(eng.tap(_abi.TAP_TX_FREQ), freq_o), "tx freq"
-        assert len(iq_g) == len(iq_o) and (len(iq_o) == 0 or np.abs(iq_g - iq_o).max() < 1e-5), "tx iq"
+        assert np.array_equal(iq_g, iq_o), "tx iq"
         # channel + RX
         x = np.concatenate([np.zeros(lead, np.complex64), iq_o, np.zeros(tail, np.complex64)])
         if rng.random() < 0.3 and len(iq_o) > 4 * (N + CP):
@@ -88,7 +91,8 @@ while time.time() < t_end:
             a, b = (0, len(x)) if rng.random() < 0.5 else sorted(rng.integers(0, len(x), 2).tolist())
             x[a:b] += (amp * np.exp(2j * np.pi * rng.uniform(-0.5, 0.5) * np.arange(b - a))).astype(np.complex64)
             desc["carrier"] = [amp, int(a), int(b)]
-        taps = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK, _abi.TAP_RX_PACKETS)
+        taps = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_SAMPLER, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK,
+                _abi.TAP_RX_PACKETS)
         mask = 0
         for t in taps:
             mask |= 1 << t
@@ -105,33 +109,31 @@ while time.time() < t_end:
                 print("   u around %d (in gpu: %s, in oracle: %s): %s" % (q0, q0 in pg, q0 in po, np.array2string(w, precision=7)))
         assert pg == po, "peaks"
         assert eng.tap(_abi.TAP_RX_FRAMES).tolist() == ro.tap(_abi.TAP_RX_FRAMES).tolist(), "frames"
-        assert np.array_equal(eng.tap(_abi.TAP_RX_CHAN_FILT), ro.tap(_abi.TAP_RX_CHAN_FILT)), "chan_filt"
+        yg, yo = eng.tap(_abi.TAP_RX_CHAN_FILT), ro.tap(_abi.TAP_RX_CHAN_FILT)
+        if not np.array_equal(yg, yo):
+            bad = np.flatnonzero(yg != yo)
+            print("chan_filt: %d of %d samples differ, first %s; gpu %s oracle %s; input there %s" % (
+                len(bad), len(yo), bad[:8].tolist(), yg[bad[:3]], yo[bad[:3]], x[bad[:3]]))
+        assert np.array_equal(yg, yo), "chan_filt"
         assert np.array_equal(eng.tap(_abi.TAP_RX_METRIC), ro.tap(_abi.TAP_RX_METRIC)), "metric"
         assert np.array_equal(eng.tap(_abi.TAP_RX_ANGLES), ro.tap(_abi.TAP_RX_ANGLES)), "angles"
         for k in ("symbols", "peaks", "frames"):
             assert eng.last_stats[k] == ro.stats[k], k
-        # decisions can legitimately differ where a float32 value sits on a slicer boundary (garbage frames,
-        # low SNR): require the float stages first, then the packets
-        worst = 0.0
-        for tap in (_abi.TAP_RX_FFT,):
+        # every float stage carries the oracle's bits: no tolerance, no exemption
+        for tap, name in ((_abi.TAP_RX_SAMPLER, "sampler"), (_abi.TAP_RX_FFT, "fft"), (_abi.TAP_RX_ACQ, "acq"),
+                          (_abi.TAP_RX_SINK, "sink")):
             a, b = ro.tap(tap), eng.tap(tap)
-            assert a.shape == b.shape, "fft shape"
-            if a.size:
-                # float32 transforms: the rounding floor of every bin scales with the symbol's largest bin
-                # (a carrier 20 dB above the signal lifts it everywhere)
-                scale = np.maximum(1.0, np.abs(a).max(axis=1, keepdims=True))
-                worst = float(np.max(np.abs(a - b) / scale))
-                assert worst <= 1e-5, "fft tol %g" % worst
-        if pk != ro.packets or eng.tap(_abi.TAP_RX_PACKETS).tobytes() != ro.tap(_abi.TAP_RX_PACKETS).tobytes():
-            # tolerate only differences confined to CRC-failed packets of the same count and lengths
-            same_shape = len(pk) == len(ro.packets) and all(a[0] == b[0] and len(a[1]) == len(b[1]) for a, b in zip(pk, ro.packets))
-            good_equal = [p for ok, p in pk if ok] == [p for ok, p in ro.packets if ok]
-            assert same_shape and good_equal, "packets"
-            print("note: CRC-failed payload bits differ (slicer boundary)", json.dumps(desc))
+            assert a.shape == b.shape, name + " shape"
+            # NaN where a coarse offset beyond the guard band makes the equaliser divide by an empty bin: same places
+            assert np.array_equal(a, b, equal_nan=True), name
+        assert pk == ro.packets, "packets"
+        assert eng.tap(_abi.TAP_RX_PACKETS).tobytes() == ro.tap(_abi.TAP_RX_PACKETS).tobytes(), "raw messages"
         for k in ("headers_ok", "packets", "crc_ok", "chained_frames"):
             assert eng.last_stats[k] == ro.stats[k], k
     except (AssertionError, engine.EngineError, ValueError) as e:
         nbad += 1
+        if os.environ.get("FUZZ_STOP"):
+            t_end = 0
         print("MISMATCH [%s]" % (e if isinstance(e, AssertionError) else "error " + str(e)[:80]), json.dumps(desc), flush=True)
     finally:
         eng.close()

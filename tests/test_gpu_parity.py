@@ -278,6 +278,19 @@ def test_set_carrier_map_live(orc):
     ref.close()
 
 
+def test_capture_without_flags(orc):
+    """A capture in which the detector never fires (noise only), on a fresh handle: the stages in front of the
+    detector still deliver their taps (found by the round-2 soak: chan_filt came back empty)."""
+    cfg = make_cfg("qpsk")
+    eng = _engine(cfg)
+    rng = np.random.default_rng(5)
+    x = (0.01 * (rng.standard_normal(30000) + 1j * rng.standard_normal(30000))).astype(np.complex64)
+    pk = _check_rx(orc, cfg, eng, x)
+    assert pk == [] and eng.last_stats["peaks"] == 0
+    assert len(eng.tap(_abi.TAP_RX_CHAN_FILT)) == len(x)
+    eng.close()
+
+
 def test_channel_parity(orc):
     cfg = make_cfg("qpsk")
     eng = _engine(cfg)
