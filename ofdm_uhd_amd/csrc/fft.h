@@ -245,13 +245,17 @@ __device__ __forceinline__ void fft_pass_tw(c32 e[8], int t, const c32* src, c32
   for (int b = 0; b < NB; b++) {
     const int j = t + b * T;  // butterfly index in [0, N/R)
     c32 v[R];
+    // LDS addresses as ONE padded base per butterfly plus compile-time offsets (they fold into the DS instructions'
+    // offset fields): lpad(j + q*STRIDE) = lpad(j) + q*(STRIDE + STRIDE/8), STRIDE being a multiple of 8
+    static_assert(FROM_REG || STRIDE % 8 == 0, "padded read offsets need STRIDE % 8 == 0");
+    const int rbase = FROM_REG ? 0 : lpad(j);
 #pragma unroll
     for (int q = 0; q < R; q++) {
       // j + q*STRIDE = t + (b + q*NB) * T
       if (FROM_REG)
         v[q] = e[b + q * NB];
       else
-        v[q] = src[lpad(j + q * STRIDE)];
+        v[q] = src[rbase + q * (STRIDE + STRIDE / 8)];
     }
     const int k = (LS == 1) ? 0 : (j % LS);
     if constexpr (PK) {
@@ -287,13 +291,17 @@ __device__ __forceinline__ void fft_pass_tw(c32 e[8], int t, const c32* src, c32
       }
     }
     const int obase = (j - k) * R + k;  // (j / LS) * LS * R + k
+    // lpad(obase + r*LS) = lpad(obase) + r*LS + (r*LS)/8: exact when LS is a multiple of 8, and for LS < 8 because the
+    // low three bits of obase (k < LS, or R*j mod 8 in a leading pass) and of r*LS never carry into bit 3
+    static_assert(LS % 8 == 0 || 8 % LS == 0, "padded write offsets");
+    const int wbase = TO_REG ? 0 : lpad(obase);
     if constexpr (INPLACE) sync();
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (TO_REG)
         e[b + r * NB] = v[r];  // LS == N/R here, so obase + r*LS = j + r*STRIDE
       else
-        dst[lpad(obase + r * LS)] = v[r];
+        dst[wbase + r * LS + ((r * LS) >> 3)] = v[r];
     }
   }
 }

@@ -170,13 +170,21 @@ struct DemodParams {
 };
 
 // LDS of one frame's workgroup: fft (2 buffers; the first doubles as the shifted spectrum, the second as
-// the |Y[i]-Y[i+2]|^2 scratch of the preamble) | hinv[occ] | dfe[occ] | constellation | reduction scratch |
-// the bits of one OFDM symbol
+// the |Y[i]-Y[i+2]|^2 scratch of the preamble) | hinv[occ] | dfe[occ] | constellation | reduction scratch (more than
+// one wave only) | the bits of one OFDM symbol | slicer grid (grid constellations only) | the sink's carrier map
 __host__ __device__ inline int demod_symbits_words(int nmap, int nbits) { return (nmap * nbits + 8 + 31) / 32 + 2; }
+// hinv doubles as the correlator scratch (occ + 2*shift + 1 floats) where the transform has one buffer
+__host__ __device__ inline int demod_hinv_len(int n, int occ, int shift) {
+  const int need = fft_onebuf(n) ? (occ + 2 * shift + 2 + 1) / 2 : 0;
+  return need > occ ? need : occ;
+}
+// reduction scratch: per-wave partials beyond one wave, per-thread terms (sequential sum) below one
+__host__ __device__ inline int demod_red_floats(int n) { return n / 8 == WAVE ? 0 : 64; }
 template <int N>
-__host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int nbits) {
-  return fft_lds_bytes(N) + 2 * occ * (int)sizeof(c32) + arity * (int)sizeof(c32) + 64 * (int)sizeof(float) +
-         demod_symbits_words(nmap, nbits) * 4 + 64 + (int)sizeof(SlicerGrid);
+__host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int nbits, int shift, bool grid) {
+  return fft_lds_bytes(N) + (demod_hinv_len(N, occ, shift) + occ) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
+         demod_red_floats(N) * (int)sizeof(float) + ((demod_symbits_words(nmap, nbits) + 3) & ~3) * 4 +
+         (grid ? (int)sizeof(SlicerGrid) : 0) + ((nmap * 2 + 3) & ~3);
 }
 
 // sum over the N/8 threads of the frame (two values at once)
@@ -271,12 +279,16 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
   // correlator scratch (occ + 2*shift + 1 floats): the second FFT buffer where there is one, else the
   // equaliser's own array -- it is rebuilt from scratch right after the correlation (block barriers between)
   float* sd = fft_onebuf(N) ? reinterpret_cast<float*>(hinv) : reinterpret_cast<float*>(fftbuf + fft_lds_points(N));
-  c32* dfe = hinv + q.occ;
+  c32* dfe = hinv + demod_hinv_len(N, q.occ, q.shift);
   c32* cst = dfe + q.occ;
   float* red = reinterpret_cast<float*>(cst + q.arity);
-  uint32_t* sbits = reinterpret_cast<uint32_t*>(red + 64);
+  uint32_t* sbits = reinterpret_cast<uint32_t*>(red + demod_red_floats(N));
   const int sbw = demod_symbits_words(q.nmap, q.nbits);
   SlicerGrid* grid = reinterpret_cast<SlicerGrid*>(sbits + ((sbw + 3) & ~3));
+  // the sink's carrier map, read once per carrier and symbol: in LDS, so that the symbol loop's only global loads
+  // are the next symbol's samples (a wave's vector-memory counter is in order: any other load's wait would wait for
+  // the prefetch too)
+  int16_t* smapL = reinterpret_cast<int16_t*>(reinterpret_cast<unsigned char*>(grid) + (q.grid ? sizeof(SlicerGrid) : 0));
   const bool use_grid = q.grid != nullptr;
 
   const int t = threadIdx.x;
@@ -302,6 +314,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
     dfe[i] = mk(1.f, 0.f);
   }
   for (int i = t; i < q.arity; i += T) cst[i] = q.constellation[i];
+  for (int i = t; i < q.nmap; i += T) smapL[i] = q.smap[i];
   if (use_grid)
     for (int i = t; i < (int)(sizeof(SlicerGrid) / 4); i += T)
       reinterpret_cast<uint32_t*>(grid)[i] = reinterpret_cast<const uint32_t*>(q.grid)[i];
@@ -351,11 +364,6 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       c32 e[8];
 #pragma unroll
       for (int m = 0; m < 8; m++) e[m] = nx[m];
-      if (k < K) {
-        const uint64_t s1 = s00 + (uint64_t)(k + 1) * (uint64_t)q.L;
-#pragma unroll
-        for (int m = 0; m < 8; m++) nx[m] = q.y[s1 + (uint64_t)(t + m * T)];
-      }
       // ---- sigmix: chan_filt * exp(j phi[n]) ---------------------------------------------
       if (k > 0) {
         base = dmul(base, RL);
@@ -396,6 +404,13 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       }
       // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
       fft_run<N, false, FftBlockSync, DEMOD_PK>(e, tl, fftbuf, q.tw, FftBlockSync());
+      // the next symbol's samples, in flight during the acquisition / sink half of this one.  (Issued after the
+      // transform: its twiddle loads wait on the in-order vector-memory counter, i.e. on everything issued before them.)
+      if (k < K) {
+        const uint64_t s1 = s00 + (uint64_t)(k + 1) * (uint64_t)q.L;
+#pragma unroll
+        for (int m = 0; m < 8; m++) nx[m] = q.y[s1 + (uint64_t)(tl + m * T)];
+      }
       __syncthreads();  // every thread is done reading the FFT buffers before Ysh (= buffer A) is overwritten
 #pragma unroll
       for (int m = 0; m < 8; m++) Ysh[(tl + m * T + N / 2) & (N - 1)] = e[m];
@@ -498,7 +513,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       float are = 0.f, aim = 0.f;
       const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
-        const int i = q.smap[c];
+        const int i = smapL[c];
         const int yi = i + q.zl + coarse;
         const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
         const c32 in = cmul(cmul(hinv[i], comp), Y);
