@@ -114,7 +114,7 @@ enum { OFDM_SYNC_PN = 0, OFDM_SYNC_FIXED = 1 };
 typedef struct ofdm_chan {
   float sigma;             /* AWGN: y = x + sigma*(g1 + j g2)/sqrt(2), g ~ N(0,1) */
   float cfo;               /* carrier offset, radians per sample: x[n] *= exp(j*cfo*n) */
-  uint64_t seed;           /* Philox-2x32-10: counter = sample index, key = hash(seed, stream_id) */
+  uint64_t seed;           /* Philox-2x32-7: counter = sample index / 2, key = hash(seed, stream_id) */
   uint64_t stream_id;      /* independent noise per stream */
   uint64_t lead_samples;   /* noise-only samples before the first packet */
   uint64_t tail_samples;   /* noise-only samples after the last packet  */

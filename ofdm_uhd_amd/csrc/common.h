@@ -191,16 +191,18 @@ __host__ __device__ __forceinline__ uint32_t pad_symbol_hash(uint64_t seed, uint
   return (uint32_t)((z >> 32) % arity);
 }
 
-// Synthetic channel noise (stands in for the radio pair; mirrored by the oracle).  Philox-2x32-10 (Salmon et
-// al., SC'11) keyed by (seed, stream); counter = sample index / 2: one call yields two 32-bit words, word 0 for
-// the even sample of the pair and word 1 for the odd one.  A sample's word gives 16 bits of Box-Muller radius and
-// 16 bits of angle -- plenty for a test channel at 30 dB, and half the integer multiplies of a call per sample.
+// Synthetic channel noise (stands in for the radio pair; mirrored by the oracle).  Philox-2x32-7 (Salmon et
+// al., SC'11; seven rounds is Random123's own reduced-round variant, known-answer vectors in tests/test_oracle.py)
+// keyed by (seed, stream); counter = sample index / 2: one call yields two 32-bit words, word 0 for the even sample
+// of the pair and word 1 for the odd one.  A sample's word gives 16 bits of Box-Muller radius and 16 bits of angle --
+// plenty for a test channel at 30 dB.  3.5 integer multiplies per sample (round 1: ten rounds per sample).
+#define CHAN_PHILOX_ROUNDS 7
 __host__ __device__ __forceinline__ uint32_t chan_key(uint64_t seed, uint64_t stream) {
   return (uint32_t)seed ^ (uint32_t)(seed >> 32) ^ ((uint32_t)stream * 0x9E3779B9u + (uint32_t)(stream >> 32) * 0x85EBCA6Bu);
 }
-__device__ __forceinline__ void philox2x32_10(uint32_t& c0, uint32_t& c1, uint32_t k) {
+__device__ __forceinline__ void philox2x32(uint32_t& c0, uint32_t& c1, uint32_t k) {
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < CHAN_PHILOX_ROUNDS; r++) {
     const uint64_t pr = (uint64_t)0xD256D193u * (uint64_t)c0;  // one v_mad_u64_u32 for both halves
     c0 = (uint32_t)(pr >> 32) ^ k ^ c1;
     c1 = (uint32_t)pr;
@@ -212,7 +214,7 @@ __device__ __forceinline__ void chan_pair_words(uint64_t idx, uint32_t key, uint
   const uint64_t pi = idx >> 1;
   w_even = (uint32_t)pi;
   w_odd = (uint32_t)(pi >> 32);
-  philox2x32_10(w_even, w_odd, key);
+  philox2x32(w_even, w_odd, key);
 }
 __device__ __forceinline__ c32 chan_add_noise(c32 x, uint32_t word, float sigma) {
   const float inv16 = 1.0f / 65536.0f;

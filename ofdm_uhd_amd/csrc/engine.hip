@@ -649,7 +649,7 @@ template <int N>
 static void launch_tx_mod(ofdm_handle* h, const TxParams& p, const uint8_t* d_framed, uint32_t uniform_spp, uint64_t nsym,
                           uint64_t lead, c32* d_out, c32* d_freq_tap, c32* d_ifft_tap) {
   constexpr int SPW = TxGeom<N>::SPW, WG = TxGeom<N>::WG;
-  const size_t shmem = (size_t)SPW * fft_lds_bytes(N) + OFDM_MAX_ARITY * sizeof(c32);  // transforms' buffers | constellation
+  const size_t shmem = (size_t)TxGeom<N>::lds_bytes();  // transforms' buffers | constellation
   const unsigned grid = (unsigned)((nsym + SPW - 1) / SPW);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N>), dim3(grid), dim3(WG), shmem, h->txs, p, d_framed,
                      h->d_framed_off.as<uint64_t>(), h->d_sym_off.as<uint64_t>(), h->d_sym_pkt.as<uint32_t>(),

@@ -202,11 +202,22 @@ __global__ void k_sym_desc(const uint64_t* __restrict__ sym_off, int npkt, uint3
 #ifndef TX_MIN_WG
 #define TX_MIN_WG 256  // (64 = one symbol per workgroup at N = 512 measured the same: the kernel is bound by the noise generator)
 #endif
+// TX_ONEBUF=1: a wave-sized symbol transforms in ONE LDS buffer (fft_run1), 20 KB instead of 39 KB per workgroup, seven
+// waves per SIMD instead of four.  Measured (C2, same box): k_tx_mod alone 2.62 -> 2.30 ms, sequential step 14.37 ->
+// 14.15 ms, but the PIPELINED step 13.6 -> 14.0 ms: the small workgroups squeeze onto compute units already full of the
+// receiver's k_sync workgroups and slow those (barrier-coupled) more than the modulator gains, where the 39 KB ones
+// wait for a unit to drain.  The headline runs pipelined, so the default stays two buffers.
+#ifndef TX_ONEBUF
+#define TX_ONEBUF 0
+#endif
 template <int N>
 struct TxGeom {
   static constexpr int T = N / 8;
   static constexpr int WG = (T > TX_MIN_WG) ? T : TX_MIN_WG;
   static constexpr int SPW = WG / T;
+  static constexpr bool ONEBUF = (TX_ONEBUF && T <= WAVE) || fft_onebuf(N);
+  static constexpr int SYM_POINTS = (ONEBUF ? 1 : 2) * fft_lds_points(N);  // c32 per symbol
+  static constexpr int lds_bytes() { return SPW * SYM_POINTS * (int)sizeof(c32) + OFDM_MAX_ARITY * (int)sizeof(c32); }
 };
 
 template <int N>
@@ -217,7 +228,7 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
              c32* __restrict__ ifft_tap) {
   constexpr int T = TxGeom<N>::T, SPW = TxGeom<N>::SPW;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  c32* lds = reinterpret_cast<c32*>(smem_raw) + (threadIdx.x / T) * (fft_lds_bufs(N) * fft_lds_points(N));
+  c32* lds = reinterpret_cast<c32*>(smem_raw) + (threadIdx.x / T) * TxGeom<N>::SYM_POINTS;
   const int t = threadIdx.x % T;
   uint64_t sym = (uint64_t)blockIdx.x * SPW + threadIdx.x / T;
   const bool active = sym < nsym;
@@ -242,7 +253,7 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
   // The symbol's slice of the framed packet (nc * nbits bits) is fetched once, as aligned dwords, into the LDS the
   // transform will use later, and the constellation sits in LDS too: each point then costs two LDS reads instead of
   // a chain of three dependent global loads.
-  c32* cst = reinterpret_cast<c32*>(smem_raw) + SPW * (fft_lds_bufs(N) * fft_lds_points(N));  // [arity], shared by the workgroup
+  c32* cst = reinterpret_cast<c32*>(smem_raw) + SPW * TxGeom<N>::SYM_POINTS;  // [arity], shared by the workgroup
   for (int i = threadIdx.x; i < p.arity; i += TxGeom<N>::WG) cst[i] = p.constellation[i];
   uint32_t* mbytes = reinterpret_cast<uint32_t*>(lds);  // this symbol's message bytes (<= N + 8 of them)
   const uint32_t nb = (uint32_t)p.nbits, bmask = (1u << nb) - 1u;
@@ -306,7 +317,10 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
 
   // up to N = 512 a symbol's N/8 threads sit inside one wave: no workgroup barrier in the exchanges
   if constexpr (T <= WAVE) {
-    fft_run<N, true, FftWaveSync, TX_PK>(e, t, lds, p.tw, FftWaveSync());
+    if constexpr (TxGeom<N>::ONEBUF)
+      fft_run1<N, true, TX_PK, FftWaveSync, FftTwTable>(e, t, lds, FftTwTable{p.tw}, FftWaveSync());
+    else
+      fft_run<N, true, FftWaveSync, TX_PK>(e, t, lds, p.tw, FftWaveSync());
   } else {
     fft_run<N, true, FftBlockSync, TX_PK>(e, t, lds, p.tw, FftBlockSync());
   }

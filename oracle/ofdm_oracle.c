@@ -702,15 +702,16 @@ int orc_tx_ex(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payl
 /* ------------------------------------------------------------------------ */
 /* synthetic channel (stands in for the UHD sink/source pair)                */
 /* ------------------------------------------------------------------------ */
-/* Philox-2x32-10 (Salmon et al., SC'11), key = stream key.  The channel draws one call per PAIR of samples
+/* Philox-2x32-7 (Salmon et al., SC'11: Random123's reduced-round variant), key = stream key.  The channel draws one call per PAIR of samples
  * (counter = sample index / 2): word 0 serves the even sample, word 1 the odd one; a sample's word gives 16 bits
  * of Box-Muller radius and 16 bits of angle. */
 static inline uint32_t chan_key(uint64_t seed, uint64_t stream) {
   return (uint32_t)seed ^ (uint32_t)(seed >> 32) ^ ((uint32_t)stream * 0x9E3779B9u + (uint32_t)(stream >> 32) * 0x85EBCA6Bu);
 }
-void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[2]) {
+#define CHAN_PHILOX_ROUNDS 7
+void orc_philox_r(uint64_t seed, uint64_t stream, uint64_t idx, int rounds, uint32_t out[2]) {
   uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), k = chan_key(seed, stream);
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < rounds; r++) {
     uint64_t p = (uint64_t)0xD256D193u * c0;
     uint32_t hi = (uint32_t)(p >> 32), lo = (uint32_t)p;
     c0 = hi ^ k ^ c1;
@@ -719,6 +720,9 @@ void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[2]) {
   }
   out[0] = c0;
   out[1] = c1;
+}
+void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[2]) {
+  orc_philox_r(seed, stream, idx, CHAN_PHILOX_ROUNDS, out);
 }
 
 int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0) {

@@ -37,6 +37,7 @@ int orc_tx_ex(const ofdm_cfg *cfg, const uint8_t *payloads, const uint64_t *payl
               int npkt, uint64_t lead, ofdm_c32 *iq_out, uint64_t iq_cap, uint64_t *nsamples_out, ofdm_c32 *freq_tap,
               uint8_t *framed_tap, uint64_t *framed_off_tap, ofdm_c32 *ifft_tap);
 void orc_philox(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[2]);
+void orc_philox_r(uint64_t seed, uint64_t stream, uint64_t idx, int rounds, uint32_t out[2]);
 int orc_channel(ofdm_c32 *iq, uint64_t n, const ofdm_chan *ch, uint64_t index0);
 orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint32_t tap_mask);
 uint64_t orc_rx_tap(const orc_rx_result *r, int tap, void *out, uint64_t cap_bytes);

@@ -53,6 +53,8 @@ def lib():
                                 C.POINTER(C.c_uint64), vp, vp, vp, vp]
         L.orc_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp]
         L.orc_philox.restype = None
+        L.orc_philox_r.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, vp]
+        L.orc_philox_r.restype = None
         L.orc_channel.argtypes = [vp, C.c_uint64, C.POINTER(_abi.ofdm_chan), C.c_uint64]
         L.orc_rx.restype = vp
         L.orc_rx.argtypes = [C.POINTER(_abi.ofdm_cfg), vp, C.c_uint64, C.c_uint32]

@@ -104,13 +104,19 @@ def test_sampler_timeout(orc):
     gap = np.zeros(1100 * (N + CP) + 37, np.complex64)
     b = orc.tx(cfg, pay[1:], lead=0, tail=(N + CP) + 2 * N)
     x = np.concatenate([a, gap, b])
-    orc.channel(x, sigma=float(np.sqrt(np.mean(np.abs(a[2 * N:]) ** 2) / 1000.0)))
-    ro = orc.rx(cfg, x)
-    pk = eng.rx(x)
-    assert eng.tap(_abi.TAP_RX_FRAMES).tolist() == ro.tap(_abi.TAP_RX_FRAMES).tolist()
-    assert int(eng.tap(_abi.TAP_RX_FRAMES)[:, 1].max()) == 1001
-    assert pk == ro.packets and [p for ok, p in pk if ok] == pay
-    assert eng.last_stats["symbols"] == ro.stats["symbols"]
+    sigma = float(np.sqrt(np.mean(np.abs(a[2 * N:]) ** 2) / 1000.0))
+    clean = 0
+    for seed in range(6):   # parity for every noise realisation; the scenario itself (time-out fired, both packets
+        xs = x.copy()       # back) is luck-dependent at N = 64 and must come up at least once
+        orc.channel(xs, sigma=sigma, seed=seed)
+        ro = orc.rx(cfg, xs)
+        pk = eng.rx(xs)
+        assert eng.tap(_abi.TAP_RX_FRAMES).tolist() == ro.tap(_abi.TAP_RX_FRAMES).tolist()
+        assert pk == ro.packets
+        assert eng.last_stats["symbols"] == ro.stats["symbols"]
+        if int(eng.tap(_abi.TAP_RX_FRAMES)[:, 1].max()) == 1001 and [p for ok, p in pk if ok] == pay:
+            clean += 1
+    assert clean >= 1
     eng.close()
 
 
