@@ -180,11 +180,14 @@ __host__ __device__ inline int demod_hinv_len(int n, int occ, int shift) {
 }
 // reduction scratch: per-wave partials beyond one wave, per-thread terms (sequential sum) below one
 __host__ __device__ inline int demod_red_floats(int n) { return n / 8 == WAVE ? 0 : 64; }
+// The sink's carrier map sits in LDS where a frame is ONE wave's work (nothing else hides a global load's latency
+// there); a multi-wave frame reads it from global memory (at N = 4096 the 4.7 KB would cost the second workgroup per CU).
+__host__ __device__ constexpr bool demod_smap_lds(int n) { return n / 8 <= WAVE; }
 template <int N>
 __host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int nbits, int shift, bool grid) {
   return fft_lds_bytes(N) + (demod_hinv_len(N, occ, shift) + occ) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
          demod_red_floats(N) * (int)sizeof(float) + ((demod_symbits_words(nmap, nbits) + 3) & ~3) * 4 +
-         (grid ? (int)sizeof(SlicerGrid) : 0) + ((nmap * 2 + 3) & ~3);
+         (grid ? (int)sizeof(SlicerGrid) : 0) + (demod_smap_lds(N) ? ((nmap * 2 + 3) & ~3) : 0);
 }
 
 // sum over the N/8 threads of the frame (two values at once)
@@ -314,7 +317,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
     dfe[i] = mk(1.f, 0.f);
   }
   for (int i = t; i < q.arity; i += T) cst[i] = q.constellation[i];
-  for (int i = t; i < q.nmap; i += T) smapL[i] = q.smap[i];
+  if constexpr (demod_smap_lds(N))
+    for (int i = t; i < q.nmap; i += T) smapL[i] = q.smap[i];
   if (use_grid)
     for (int i = t; i < (int)(sizeof(SlicerGrid) / 4); i += T)
       reinterpret_cast<uint32_t*>(grid)[i] = reinterpret_cast<const uint32_t*>(q.grid)[i];
@@ -513,7 +517,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       float are = 0.f, aim = 0.f;
       const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
-        const int i = smapL[c];
+        const int i = demod_smap_lds(N) ? smapL[c] : q.smap[c];
         const int yi = i + q.zl + coarse;
         const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
         const c32 in = cmul(cmul(hinv[i], comp), Y);
