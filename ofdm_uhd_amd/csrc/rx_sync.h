@@ -257,19 +257,46 @@ struct F3 {
   float a, b, c;
 };
 
+// The same network on several values at once, spelled as v_add_f32 with a DPP source (one instruction per step and
+// value; from the builtin the compiler emits v_mov_b32_dpp + a packed add per pair of values plus the moves to pair
+// them up: 89 instead of 36 instructions for the six scans of block_scan3_sum3).  A lane whose DPP source lies outside
+// its row keeps its value (bound_ctrl off), exactly like `v += dpp_f(v)` above: same sums, bit for bit.  Inline asm is
+// invisible to the hazard recogniser: a VGPR written by a VALU instruction needs two wait states before a DPP read, so
+// consecutive steps of one value are kept three instructions apart (or separated by s_nop 1).
+#define DPP_STEP3(CTRL, MASK)                                                        \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"          \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"          \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"
+__device__ __forceinline__ void wave_incl_scan3_f32(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t" DPP_STEP3("row_shr:1", "0xf") DPP_STEP3("row_shr:2", "0xf") DPP_STEP3("row_shr:4", "0xf")
+                   DPP_STEP3("row_shr:8", "0xf") DPP_STEP3("row_bcast:15", "0xa") DPP_STEP3("row_bcast:31", "0xc")
+               : "+v"(a), "+v"(b), "+v"(c));
+}
+#define DPP_STEP2(CTRL, MASK)                                                        \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"          \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t"          \
+  "s_nop 0\n\t"
+__device__ __forceinline__ void wave_incl_scan2_f32(float& a, float& b) {
+  asm volatile("s_nop 1\n\t" DPP_STEP2("row_shr:1", "0xf") DPP_STEP2("row_shr:2", "0xf") DPP_STEP2("row_shr:4", "0xf")
+                   DPP_STEP2("row_shr:8", "0xf") DPP_STEP2("row_bcast:15", "0xa") DPP_STEP2("row_bcast:31", "0xc")
+               : "+v"(a), "+v"(b));
+}
+#define DPP_STEP1(CTRL, MASK) "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\ts_nop 1\n\t"
+__device__ __forceinline__ float wave_incl_scan1_f32(float a) {
+  asm volatile("s_nop 1\n\t" DPP_STEP1("row_shr:1", "0xf") DPP_STEP1("row_shr:2", "0xf") DPP_STEP1("row_shr:4", "0xf")
+                   DPP_STEP1("row_shr:8", "0xf") DPP_STEP1("row_bcast:15", "0xa") DPP_STEP1("row_bcast:31", "0xc")
+               : "+v"(a));
+  return a;
+}
+
 // Block-wide (4 waves) scans / sums.  Each call has ONE barrier; `scratch` must not be a region
 // another call of the same tile iteration used since the last-but-one barrier (callers rotate
 // three regions).
 __device__ __forceinline__ void block_scan3_sum3(F3 v, F3 s, float* scratch, F3* excl, F3* sum) {
   const int lane = lane_id(), w = wave_id();
-  F3 inc;
-  inc.a = wave_incl_scan_f32(v.a);
-  inc.b = wave_incl_scan_f32(v.b);
-  inc.c = wave_incl_scan_f32(v.c);
-  F3 rs;
-  rs.a = wave_incl_scan_f32(s.a);
-  rs.b = wave_incl_scan_f32(s.b);
-  rs.c = wave_incl_scan_f32(s.c);
+  F3 inc = v, rs = s;
+  wave_incl_scan3_f32(inc.a, inc.b, inc.c);
+  wave_incl_scan3_f32(rs.a, rs.b, rs.c);
   if (lane == WAVE - 1) {
     scratch[w * 6 + 0] = inc.a;
     scratch[w * 6 + 1] = inc.b;
@@ -298,8 +325,8 @@ __device__ __forceinline__ void block_scan3_sum3(F3 v, F3 s, float* scratch, F3*
 }
 __device__ __forceinline__ void block_scan1_sum1(float v, float s, float* scratch, float* excl, float* sum) {
   const int lane = lane_id(), w = wave_id();
-  const float inc = wave_incl_scan_f32(v);
-  const float rs = wave_incl_scan_f32(s);
+  float inc = v, rs = s;
+  wave_incl_scan2_f32(inc, rs);
   if (lane == WAVE - 1) {
     scratch[w * 2 + 0] = inc;
     scratch[w * 2 + 1] = rs;
@@ -588,31 +615,38 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       continue;
     }
     // ---- 4. float32 Schmidl-Cox sums, anchored at the tile start --------------------------
-    float pfr[SYNC_V], pfi[SYNC_V], pfe[SYNC_V];
+    // (P as a packed pair per sample: the correlator product and the running sums are two v_pk_*_f32 each)
+    cv pri[SYNC_V];
+    float pfe[SYNC_V];
     F3 tsum = {0.f, 0.f, 0.f};
     F3 anc = {0.f, 0.f, 0.f};
     if (!masked) {
+      cv tri = {0.f, 0.f};
+      float te = 0.f;
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
-        const c32 a = ys[yb + j];
-        const c32 d1 = ys[yb1 + j];
-        const c32 d2 = ys[yb2 + j];
-        tsum.a += fmaf(a.re, d1.re, a.im * d1.im) - fmaf(d1.re, d2.re, d1.im * d2.im);
-        tsum.b += fmaf(a.im, d1.re, -(a.re * d1.im)) - fmaf(d1.im, d2.re, -(d1.re * d2.im));
-        tsum.c += fmaf(a.re, a.re, a.im * a.im) - fmaf(d1.re, d1.re, d1.im * d1.im);
-        pfr[j] = tsum.a;
-        pfi[j] = tsum.b;
-        pfe[j] = tsum.c;
+        const cv a = cv_of(ys[yb + j]);
+        const cv d1 = cv_of(ys[yb1 + j]);
+        const cv d2 = cv_of(ys[yb2 + j]);
+        tri = tri + (pk_cmul_tw<true>(a, d1) - pk_cmul_tw<true>(d1, d2));  // a conj(d1) - d1 conj(d2)
+        te += fmaf(a.x, a.x, a.y * a.y) - fmaf(d1.x, d1.x, d1.y * d1.y);
+        pri[j] = tri;
+        pfe[j] = te;
       }
+      tsum.a = tri.x;
+      tsum.b = tri.y;
+      tsum.c = te;
       // anchor: the window sums at the sample before the tile, summed afresh from the history
+      cv ari = {0.f, 0.f};
       for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
         const int sa = ring_wrap(rbase + m, R);
-        const c32 a = ys[sync_lp(sa)];
-        const c32 d1 = ys[sync_lp(ring_wrap(sa - D, R))];
-        anc.a += fmaf(a.re, d1.re, a.im * d1.im);
-        anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
-        anc.c += fmaf(a.re, a.re, a.im * a.im);
+        const cv a = cv_of(ys[sync_lp(sa)]);
+        const cv d1 = cv_of(ys[sync_lp(ring_wrap(sa - D, R))]);
+        ari = ari + pk_cmul_tw<true>(a, d1);
+        anc.c += fmaf(a.x, a.x, a.y * a.y);
       }
+      anc.a = ari.x;
+      anc.b = ari.y;
     } else {
 #pragma unroll
       for (int j = 0; j < SYNC_V; j++) {
@@ -634,8 +668,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
         tsum.a += nr - orr;
         tsum.b += ni - oi;
         tsum.c += ne - oe;
-        pfr[j] = tsum.a;
-        pfi[j] = tsum.b;
+        pri[j].x = tsum.a;
+        pri[j].y = tsum.b;
         pfe[j] = tsum.c;
       }
       for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
@@ -655,19 +689,28 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     STAMP(4);
     float Mv[SYNC_V];
     const int mb = sync_lp(SYNC_V * tl);
+    cv bri;  // window sums at the sample before this thread's first
+    bri.x = anch.a + ex3.a;
+    bri.y = anch.b + ex3.b;
+    const float be = anch.c + ex3.c;
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
-      const float pre = anch.a + ex3.a + pfr[j];
-      const float pim = anch.b + ex3.b + pfi[j];
-      const float r = anch.c + ex3.c + pfe[j];
-      const float num = fmaf(pre, pre, pim * pim);
-      const float den = r * r;
-      float m = (den > 0.0f) ? num * __builtin_amdgcn_rcpf(den) : 0.0f;  // pre-selection only: 1-ulp reciprocal (an IEEE divide costs ten instructions)
-      if (!(m <= 1024.0f)) m = 1024.0f;
-      if (masked && (t0s + SYNC_V * tl + j < mvalid)) m = 0.0f;
+      const cv pq = bri + pri[j];
+      const float r = be + pfe[j];
+      const float num = fmaf(pq.x, pq.x, pq.y * pq.y);
+      // pre-selection only: 1-ulp reciprocal (an IEEE divide costs ten instructions).  R = 0 means P = 0 too: the
+      // floor on the denominator gives the 0/0 -> 0 of the normative metric without a compare and select.
+      float m = num * __builtin_amdgcn_rcpf(fmaxf(r * r, 1e-37f));
+      m = fminf(m, 1024.0f);  // (NaN -- Inf/Inf on garbage input -- goes to 1024 as well: fminf returns the number)
       Mv[j] = m;
-      mt[mb + j] = m;
     }
+    if (masked) {  // (a warm-up tile: samples whose windows reach before the segment's first loaded sample)
+#pragma unroll
+      for (int j = 0; j < SYNC_V; j++)
+        if (t0s + SYNC_V * tl + j < mvalid) Mv[j] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < SYNC_V; j++) mt[mb + j] = Mv[j];
     __syncthreads();  // B4
     STAMP(5);
 
@@ -735,7 +778,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     }
     if (p.exact_all) amask = (1u << nv) - 1u;
     {
-      const float bw = wave_incl_scan_f32(floc * wgt);
+      const float bw = wave_incl_scan1_f32(floc * wgt);
       if (lane_id() == WAVE - 1) scC[wave_id()] = bw;
     }
     const int anyc = __syncthreads_or(amask != 0);  // B6
@@ -774,7 +817,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
     }
     {
-      const float a = wave_incl_scan_f32(fpre * wgt), b = wave_incl_scan_f32(fpost * wgt);
+      float a = fpre * wgt, b = fpost * wgt;
+      wave_incl_scan2_f32(a, b);
       if (lane_id() == WAVE - 1) {
         scA[2 * wave_id()] = a;
         scA[2 * wave_id() + 1] = b;
