@@ -53,7 +53,7 @@ struct SyncRec {
 
 struct SyncParams {
   int N, D, CP;
-  int HY;         // y history the metric needs before a tile (2*D + CP, multiple of 8)
+  int HY;         // y history the metric needs before a tile (2*D, multiple of 8)
   int HM;         // M history (CP)
   int R;          // samples in the LDS ring of y (multiple of 8)
   int tiles_per_seg, nwarm;
@@ -514,7 +514,10 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
 #endif
 // W: workgroups per CU the register allocation aims at -- 3 when the LDS footprint allows three, else 2 (long
 // symbols: the y history alone is N+CP samples).
-template <int W>
+// STATIC (history no longer than a tile: N <= 1024 at the usual prefix lengths): the LDS holds [history | tile] at fixed
+// places and the newest R - T samples are copied to the front after each tile's last read -- every LDS address of the
+// tile loop is then one per-thread base plus uniform offsets, where the ring costs a wrap per access.
+template <int W, bool STATIC>
 __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -553,13 +556,15 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   // weight of this thread's 8 samples in the tile summary of the detector average
   const float decay_f = (float)p.decay;
   const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
-  int rbase = 0;  // the ring slot of the tile's first sample
+  int rbase = STATIC ? R - SYNC_TILE : 0;  // the slot of the tile's first sample
+  auto RW = [R](int s_) { return STATIC ? s_ : ring_wrap(s_, R); };
   // the next tile of y, fetched a tile ahead: its HBM latency hides behind the metric phase
   float4 ypre[SYNC_V / 2];
   bool have_pre = false;
   __syncthreads();
 
-  for (uint64_t tile = tile_first; tile < tile_own1; tile++, rbase = (rbase + T >= R) ? rbase + T - R : rbase + T) {
+  for (uint64_t tile = tile_first; tile < tile_own1;
+       tile++, rbase = STATIC ? rbase : ((rbase + T >= R) ? rbase + T - R : rbase + T)) {
     // Opaque copy of the thread index, renewed every tile: otherwise the compiler hoists every
     // tid-dependent LDS address of the loop body out of the loop and then spills them.
     int tl = tid;
@@ -574,7 +579,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     if (have_pre) {
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) {
-        const int li = sync_lp(ring_wrap(rbase + 2 * (tl + r * SYNC_THREADS), R));
+        const int li = sync_lp(RW(rbase + 2 * (tl + r * SYNC_THREADS)));
         ys[li] = mk(ypre[r].x, ypre[r].y);
         ys[li + 1] = mk(ypre[r].z, ypre[r].w);
       }
@@ -583,7 +588,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) {
         const float4 v = src[tl + r * SYNC_THREADS];
-        const int li = sync_lp(ring_wrap(rbase + 2 * (tl + r * SYNC_THREADS), R));
+        const int li = sync_lp(RW(rbase + 2 * (tl + r * SYNC_THREADS)));
         ys[li] = mk(v.x, v.y);
         ys[li + 1] = mk(v.z, v.w);
       }
@@ -594,7 +599,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
         const uint64_t n = t0 + (uint64_t)i;
         c32 v = mk(0.f, 0.f);
         if (n < p.nsamples) v = p.y[n];
-        ys[sync_lp(ring_wrap(rbase + i, R))] = v;
+        ys[sync_lp(RW(rbase + i))] = v;
       }
     }
     have_pre = false;
@@ -607,8 +612,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     STAMP(1);
     __syncthreads();  // B2: the tile's y is in the ring
     STAMP(2);
-    const int ybs = ring_wrap(rbase + SYNC_V * tl, R);
-    const int yb = sync_lp(ybs), yb1 = sync_lp(ring_wrap(ybs - D, R)), yb2 = sync_lp(ring_wrap(ring_wrap(ybs - D, R) - D, R));
+    const int ybs = RW(rbase + SYNC_V * tl);
+    const int yb = sync_lp(ybs), yb1 = sync_lp(RW(ybs - D)), yb2 = sync_lp(RW(RW(ybs - D) - D));
 
     if (SYNC_ABLATE(p, 2)) {
       __syncthreads();
@@ -639,9 +644,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       // anchor: the window sums at the sample before the tile, summed afresh from the history
       cv ari = {0.f, 0.f};
       for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
-        const int sa = ring_wrap(rbase + m, R);
+        const int sa = RW(rbase + m);
         const cv a = cv_of(ys[sync_lp(sa)]);
-        const cv d1 = cv_of(ys[sync_lp(ring_wrap(sa - D, R))]);
+        const cv d1 = cv_of(ys[sync_lp(RW(sa - D))]);
         ari = ari + pk_cmul_tw<true>(a, d1);
         anc.c += fmaf(a.x, a.x, a.y * a.y);
       }
@@ -674,9 +679,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
       for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
         if (t0s + m >= qvalid) {
-          const int sa = ring_wrap(rbase + m, R);
+          const int sa = RW(rbase + m);
           const c32 a = ys[sync_lp(sa)];
-          const c32 d1 = ys[sync_lp(ring_wrap(sa - D, R))];
+          const c32 d1 = ys[sync_lp(RW(sa - D))];
           anc.a += fmaf(a.re, d1.re, a.im * d1.im);
           anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
           anc.c += fmaf(a.re, a.re, a.im * a.im);
@@ -687,6 +692,11 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     F3 ex3, anch;
     block_scan3_sum3(tsum, anc, scA, &ex3, &anch);  // B3
     STAMP(4);
+    if constexpr (STATIC) {
+      // every read of this tile's y happened before B3: slide the newest R - T samples to the front.  (Source and
+      // destination do not overlap, R - T <= T; the next tile's store comes after the barriers below.)
+      for (int c = tl; c < R - T; c += SYNC_THREADS) ys[sync_lp(c)] = ys[sync_lp(T + c)];
+    }
     float Mv[SYNC_V];
     const int mb = sync_lp(SYNC_V * tl);
     cv bri;  // window sums at the sample before this thread's first
