@@ -190,12 +190,63 @@ __host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int
          (grid ? (int)sizeof(SlicerGrid) : 0) + (demod_smap_lds(N) ? ((nmap * 2 + 3) & ~3) : 0);
 }
 
+// Two wave-wide sums in the normative order (oracle: lane_tree_sum -- partner = lane ^ d for d = 32, 16, ... 1, each
+// level adding own + partner), without LDS traffic: gfx950's v_permlane32/16_swap exchange half-waves / rows, the
+// levels inside a row of 16 are DPP row shifts (the lanes below the partner take the left shift, those above the right
+// one: two bank-masked instructions per level) and quad permutations.  Same tree as six ds_bpermute round trips per
+// value, at a tenth of their latency.  (Inline asm: two wait states separate a VGPR write from its DPP / swap read.)
+__device__ __forceinline__ void wave_sum2_tree(float& a, float& b) {
+  float t0, t1;
+  asm volatile(
+      "v_mov_b32 %2, %0\n\t"
+      "v_mov_b32 %3, %1\n\t"
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %2\n\t"
+      "v_permlane32_swap_b32 %1, %3\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "v_add_f32 %1, %1, %3\n\t"
+      "v_mov_b32 %2, %0\n\t"
+      "v_mov_b32 %3, %1\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %2\n\t"
+      "v_permlane16_swap_b32 %1, %3\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "v_add_f32 %1, %1, %3\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %2, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %3, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(a), "+v"(b), "=&v"(t0), "=&v"(t1));
+}
+
+#ifndef DEMOD_TREE_DPP
+#define DEMOD_TREE_DPP 1
+#endif
 // sum over the N/8 threads of the frame (two values at once)
 template <int T>
 __device__ __forceinline__ void block_sum2_f(float& a, float& b, float* red) {
   if (T >= WAVE) {
+#if DEMOD_TREE_DPP
+    wave_sum2_tree(a, b);
+#else
     a = wave_sum(a);
     b = wave_sum(b);
+#endif
     if (T > WAVE) {
       if (lane_id() == 0) {
         red[2 * wave_id()] = a;
