@@ -197,18 +197,21 @@ __global__ void k_sym_desc(const uint64_t* __restrict__ sym_off, int npkt, uint3
 }
 
 // ---------------------------------------------------------------------------------
-// modulator.  WG = max(256, N/8) threads = SPW symbols of N/8 threads each.
+// modulator.  WG = max(512, N/8) threads = SPW symbols of N/8 threads each.
 // ---------------------------------------------------------------------------------
 #ifndef TX_MIN_WG
-#define TX_MIN_WG 256  // (64 = one symbol per workgroup at N = 512 measured the same: the kernel is bound by the noise generator)
+#define TX_MIN_WG 512
 #endif
-// TX_ONEBUF=1: a wave-sized symbol transforms in ONE LDS buffer (fft_run1), 20 KB instead of 39 KB per workgroup, seven
-// waves per SIMD instead of four.  Measured (C2, same box): k_tx_mod alone 2.62 -> 2.30 ms, sequential step 14.37 ->
-// 14.15 ms, but the PIPELINED step 13.6 -> 14.0 ms: the small workgroups squeeze onto compute units already full of the
-// receiver's k_sync workgroups and slow those (barrier-coupled) more than the modulator gains, where the 39 KB ones
-// wait for a unit to drain.  The headline runs pipelined, so the default stays two buffers.
+// A wave-sized symbol transforms in ONE LDS buffer (fft_run1: in-place middle passes, wave-level fences), and the
+// workgroup is 512 threads: eight such symbols, 39 KB.  Measured at C2 on one box, alternating:
+//   256 threads, two buffers (39 KB, 4 waves/SIMD)   k_tx_mod 2.62 ms   pipelined step 13.35-13.48 ms
+//   256 threads, one buffer  (20 KB, 7 waves/SIMD)   k_tx_mod 2.30 ms   pipelined step 13.9-14.0 ms
+//   512 threads, one buffer  (39 KB, 6 waves/SIMD)   k_tx_mod 2.41 ms   pipelined step 13.30 ms
+// The kernel is latency-bound (one short-lived wave per symbol: a chain of dependent loads, then the transform), so it
+// wants waves; but 20 KB workgroups squeeze onto compute units already full of the receiver's k_sync workgroups and
+// slow those barrier-coupled waves more than the modulator gains, while 39 KB ones wait for a unit to drain.
 #ifndef TX_ONEBUF
-#define TX_ONEBUF 0
+#define TX_ONEBUF 1
 #endif
 template <int N>
 struct TxGeom {
@@ -230,7 +233,11 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   c32* lds = reinterpret_cast<c32*>(smem_raw) + (threadIdx.x / T) * TxGeom<N>::SYM_POINTS;
   const int t = threadIdx.x % T;
-  uint64_t sym = (uint64_t)blockIdx.x * SPW + threadIdx.x / T;
+  // A symbol whose threads fill whole waves is the same for every lane of a wave: saying so (readfirstlane) moves the
+  // symbol's index arithmetic -- packet, bit offsets, message and output addresses -- from the vector to the scalar unit.
+  uint32_t slot = threadIdx.x / T;
+  if constexpr (T >= WAVE) slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+  uint64_t sym = (uint64_t)blockIdx.x * SPW + slot;
   const bool active = sym < nsym;
   if (!active) sym = nsym - 1;
 
@@ -247,6 +254,10 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
   } else {
     pkt = sym_pkt[sym];
     s = (uint32_t)(sym - sym_off[pkt]);
+  }
+  if constexpr (T >= WAVE) {
+    pkt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pkt);
+    s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
   }
 
   // ---- digital_ofdm_mapper_bcv::work for this symbol ---------------------------------------------------------
