@@ -15,7 +15,11 @@ rng = np.random.default_rng(seed)
 maps = [b["carrier_map"][:50] for b in json.load(open(os.path.join(ROOT, "tests/golden/sense_blocks.json")))["blocks"]]
 t_end = time.time() + budget
 ncase = nbad = 0
-for mod, N, occ, CP in (("qpsk", 512, 200, 128), ("qam16", 1024, 600, 256)):
+for gi, (mod, N, occ, CP) in enumerate((("qpsk", 512, 200, 128), ("qam16", 1024, 600, 256))):
+    if os.environ.get("FUZZ_GEOM") not in (None, str(gi)):
+        continue
+    rng = np.random.default_rng([seed, gi])   # (per geometry: the second one's cases do not depend on how many the first ran)
+    t_beat = time.time() + 30
     cfg = make_cfg(mod, N, occ, CP)
     eng = engine.Engine(cfg=cfg)
     carriers = ""
@@ -23,6 +27,9 @@ for mod, N, occ, CP in (("qpsk", 512, 200, 128), ("qam16", 1024, 600, 256)):
     t_geo = time.time() + budget / 2
     while time.time() < t_geo:
         ncase += 1
+        if time.time() > t_beat:
+            print("... %d calls, %d mismatches" % (ncase, nbad), flush=True)
+            t_beat = time.time() + 30
         if N == 512 and rng.random() < 0.15:
             carriers = "" if rng.random() < 0.4 else maps[int(rng.integers(0, len(maps)))]
             eng.set_carrier_map(carriers)
@@ -47,6 +54,15 @@ for mod, N, occ, CP in (("qpsk", 512, 200, 128), ("qam16", 1024, 600, 256)):
             eng.set_taps(*taps)
             ro = orc.rx(cfg, x)
             pk = eng.rx(x)
+            pg, po = eng.tap(_abi.TAP_RX_PEAKS).tolist(), ro.tap(_abi.TAP_RX_PEAKS).tolist()
+            if pg != po:
+                d = sorted(set(pg) ^ set(po))[:6]
+                print("peaks differ: gpu %d oracle %d; symmetric difference (first) %s" % (len(pg), len(po), d))
+                u = orc.rx(cfg, x, 1 << _abi.TAP_RX_METRIC).tap(_abi.TAP_RX_METRIC)
+                for q0 in d[:3]:
+                    print("   u around %d (in gpu: %s, in oracle: %s): %s" % (q0, q0 in pg, q0 in po, np.array2string(u[max(0, q0 - 40):q0 + 8], precision=6, max_line_width=200)))
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.save(os.path.join(ROOT, "gpurun_out", "reuse_fail_%d.npy" % ncase), x)
             for k in ("symbols", "peaks", "frames", "headers_ok", "packets", "chained_frames"):
                 assert eng.last_stats[k] == ro.stats[k], k
             assert pk == ro.packets, "packets"
@@ -57,6 +73,8 @@ for mod, N, occ, CP in (("qpsk", 512, 200, 128), ("qam16", 1024, 600, 256)):
                 assert np.array_equal(r["msgs"], o["msgs"]), "sense msgs"
         except (AssertionError, engine.EngineError, ValueError) as e:
             nbad += 1
+            if os.environ.get("FUZZ_STOP"):
+                t_end = t_geo = 0
             print("MISMATCH [%s]" % (e if isinstance(e, AssertionError) else "error " + str(e)[:90]), json.dumps(desc), flush=True)
     eng.close()
 print("fuzz_reuse: %d calls, %d mismatches, seed %d" % (ncase, nbad, seed))

@@ -21,21 +21,22 @@ def sources_sha():
     return h.hexdigest()[:16]
 
 
-KERNELS = {"k_frame_pack": "k_frame_pack", "k_tx_mod": "k_tx_mod", "k_chan_filter": "k_chan_filter", "k_sync": "k_sync",
-           "k_rx_demod": "k_rx_demod", "k_deframe_write": "k_deframe", "k_sense<": "k_sense"}
+KERNELS = {"k_frame_pack": "k_frame_pack", "k_tx_mod": "k_tx_mod", "k_chan_filter": "k_chan_filter", "k_sync<": "k_sync",
+           "k_sync_exact": "k_sync_exact", "k_rx_demod": "k_rx_demod", "k_deframe_write": "k_deframe", "k_sense<": "k_sense"}
 
 
 def per_kernel(path, counter):
     fs = glob.glob(path + "/*/*_counter_collection.csv")
-    tot, n = collections.defaultdict(float), collections.Counter()
+    tot, steps = collections.defaultdict(float), 0
     for r in csv.DictReader(open(fs[0])):
         if r["Counter_Name"] != counter:
             continue
+        if "k_rx_demod" in r["Kernel_Name"]:
+            steps += 1  # (one launch per step; k_sync_exact has two: per-step sums, not per-launch averages)
         for pat, name in KERNELS.items():
             if pat in r["Kernel_Name"]:
                 tot[name] += float(r["Counter_Value"])
-                n[name] += 1
-    return {k: tot[k] / n[k] for k in tot}
+    return {k: tot[k] / steps for k in tot}
 
 
 def main():
@@ -43,7 +44,7 @@ def main():
     rd, wr = per_kernel(d + "/pmc3", "FETCH_SIZE"), per_kernel(d + "/pmc4", "WRITE_SIZE")
     out = {"source": tag, "sources_sha": sources_sha(), "config": cfg, "symbols_per_launch": nsym,
            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_job_prof.sh); "
-                  "KiB per dispatch; FETCH_SIZE doubled (MI355X_MICROARCH.md, gfx950 wide reads)",
+                  "KiB per step; FETCH_SIZE doubled (MI355X_MICROARCH.md, gfx950 wide reads)",
            "bytes_per_symbol": {k: {"read": 2.0 * rd.get(k, 0.0) * 1024.0 / nsym, "write": wr.get(k, 0.0) * 1024.0 / nsym}
                                 for k in sorted(set(rd) | set(wr))}}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg), "w") as f:
