@@ -1099,52 +1099,59 @@ __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
     float peak_val = -INFINITY;
     uint64_t peak_ind = 0;
     uint64_t peak_off = 0;  // where the peak's P sits in the candidate arrays (read only when a flag is raised)
+    // the pending peak lies in the piece being walked, pk_k values in (its sample index and candidate offset are
+    // formed when the piece ends or a flag is raised: no 64-bit bookkeeping per value)
+    bool pk_cur = false;
+    uint32_t pk_k = 0;
     bool open_at_stream_end = false;
     for (;;) {
-      const uint64_t len = pc.end - pc.start + 1;
-      for (uint64_t kb = 0; kb < len; kb += 8) {
+      const uint32_t len = (uint32_t)(pc.end - pc.start + 1);  // a piece lies inside one tile
+      const float* __restrict__ up = p.cand_u + pc.val_off;
+      for (uint32_t kb = 0; kb < len; kb += 8) {
         // eight values per trip: the loads are independent of the state machine, so issue them together
         float ub[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) ub[e] = (kb + e < len) ? p.cand_u[pc.val_off + kb + e] : 0.0f;
+        for (int e = 0; e < 8; e++) ub[e] = up[(kb + e < len) ? kb + e : len - 1];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          const uint64_t k = kb + e;
-          if (k >= len) break;
-          const float u = ub[e];
-          const uint64_t i = pc.start + k;
-          for (;;) {
-            if (state == 0) {
-              if (u > avg * p.rise) {
-                state = 1;
-                continue;
+          const uint32_t k = kb + e;
+          if (k < len) {
+            // gr_peak_detector_fb's automaton on one value, without branches on the common paths:
+            //   searching: u > avg*rise opens a run, and the value is then looked at as the run's first;
+            //   in a run: a new maximum is recorded; else u > avg*fall keeps the run; else the run ends -- a flag at
+            //   the recorded maximum -- and the SAME value is looked at again by the searching detector.
+            // The average moves exactly once per value on every path.
+            const float u = ub[e];
+            bool s1 = (state != 0) || (u > avg * p.rise);
+            bool newpk = s1 && (u > peak_val);
+            if (s1 && !newpk && !(u > avg * p.fall)) {  // the run ends here (once per run)
+              const uint64_t ind = pk_cur ? pc.start + pk_k : peak_ind;
+              const uint64_t off = pk_cur ? pc.val_off + pk_k : peak_off;
+              if (WRITE) {
+                p.peaks[wbase + nflag] = ind;
+                p.peak_P[wbase + nflag] = p.cand_P[off];
+              } else if (nflag < PEAK_STASH) {
+                p.stash_peaks[g0 * PEAK_STASH + nflag] = ind;
+                p.stash_P[g0 * PEAK_STASH + nflag] = p.cand_P[off];
               }
-              avg = p.alpha * u + one_m_alpha * avg;
-              break;
+              nflag++;
+              peak_val = -INFINITY;
+              pk_cur = false;
+              s1 = u > avg * p.rise;
+              newpk = s1 && (u > peak_val);
             }
-            if (u > peak_val) {
-              peak_val = u;
-              peak_ind = i;
-              peak_off = pc.val_off + k;
-              avg = p.alpha * u + one_m_alpha * avg;
-              break;
-            }
-            if (u > avg * p.fall) {
-              avg = p.alpha * u + one_m_alpha * avg;
-              break;
-            }
-            if (WRITE) {
-              p.peaks[wbase + nflag] = peak_ind;
-              p.peak_P[wbase + nflag] = p.cand_P[peak_off];
-            } else if (nflag < PEAK_STASH) {
-              p.stash_peaks[g0 * PEAK_STASH + nflag] = peak_ind;
-              p.stash_P[g0 * PEAK_STASH + nflag] = p.cand_P[peak_off];
-            }
-            nflag++;
-            state = 0;
-            peak_val = -INFINITY;
+            peak_val = newpk ? u : peak_val;
+            pk_k = newpk ? k : pk_k;
+            pk_cur = pk_cur || newpk;
+            avg = p.alpha * u + one_m_alpha * avg;
+            state = s1 ? 1 : 0;
           }
         }
+      }
+      if (pk_cur) {
+        peak_ind = pc.start + pk_k;
+        peak_off = pc.val_off + pk_k;
+        pk_cur = false;
       }
       // does the interval continue in the next tile?
       const uint64_t gn = g + 1;
