@@ -83,3 +83,33 @@ def test_feed_other_geometry(orc):
         got += s.feed(iq[a:a + 250000])
     got += s.flush()
     assert got == want and sum(ok for ok, _ in want) >= 8
+
+
+def test_feed_after_reset_carrier_map(orc):
+    """reset_carrier_map to a sparse sensed map (packets then take up to occ/ncar times more symbols) and then
+    feed() in chunks: the carried span must follow the live map, or a long packet is delivered truncated."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sense_blocks.json")) as f:
+        maps = [b["carrier_map"][:50] for b in json.load(f)["blocks"]]
+    carriers = min(maps, key=lambda m: sum(bin(int(c, 16)).count("1") for c in m))   # the sparsest recorded map
+    ncar = sum(bin(int(c, 16)).count("1") for c in carriers)
+    assert 0 < ncar < 150
+    cfg = make_cfg("qpsk", 512, 200, 128, carriers=carriers)
+    pay = make_payloads(8, [4091, 300, 4091, 1500, 4091, 20, 2500, 4091], seed=11)
+    parts = [np.zeros(3000, np.complex64)]
+    for i in range(0, 8, 2):
+        parts += [orc.tx(cfg, pay[i:i + 2]), np.zeros(20000, np.complex64)]
+    iq = np.concatenate(parts)
+    orc.channel(iq, sigma=float(np.sqrt(np.mean(np.abs(parts[1]) ** 2) / 10 ** 3.0)), seed=5)
+    d = _demod()
+    d.reset_carrier_map(carriers)
+    want = d.work(iq)
+    assert want == orc.rx(cfg, iq).packets and sum(ok for ok, _ in want) >= 5
+    s = _demod()
+    s.reset_carrier_map(carriers)
+    got = []
+    for a in range(0, len(iq), 60000):          # shorter than one maximum-length packet on this map
+        got += s.feed(iq[a:a + 60000])
+    got += s.flush()
+    assert got == want
