@@ -287,6 +287,21 @@ __device__ __forceinline__ dc dmul(dc a, dc b) {
   r.im = a.re * b.im + a.im * b.re;
   return r;
 }
+__device__ __forceinline__ double f64_uniform(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float f32_uniform(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ dc dc_uniform(dc v) {
+  dc r;
+  r.re = f64_uniform(v.re);
+  r.im = f64_uniform(v.im);
+  return r;
+}
 // exp(j ph) for the NCO, bit-reproducible: wrap to [-pi, pi], reduce by multiples of pi/2 (two-part constant),
 // fdlibm kernel polynomials with explicit fma() -- the CPU restatement evaluates the same operations.
 __device__ __noinline__ dc dexpj(double ph) {
@@ -388,8 +403,9 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
     //   n - p + 1 = k*L - N + 2 + t + m*T   =>   exp(j phi) = A * RL^k * RT^m
     const double st = q.step[j];
     dc A = dexpj(q.Phi[j] + st * (double)(2 - N + t));
-    const dc RL = dexpj(st * (double)q.L);
-    const dc RT = dexpj(st * (double)T);
+    // (the two step phasors are the same in every lane: held in scalar registers, eight vector registers fewer)
+    const dc RL = dc_uniform(dexpj(st * (double)q.L));
+    const dc RT = dc_uniform(dexpj(st * (double)T));
     // the preamble symbol ends ON the flag: its samples before p belong to the previous segment(s)
     const bool pre_simple = (j == 0) || (q.peaks[j - 1] <= s00);
     dc Ap = {1.0, 0.0}, RTp = {1.0, 0.0};
@@ -540,7 +556,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
           const float af = (float)a;
           float sn, cs;
           det_sincosf(af, &sn, &cs);
-          comp = mk(cs, sn);
+          comp = mk(f32_uniform(cs), f32_uniform(sn));
         } else {
           comp = mk(1.0f, 0.0f);
         }
@@ -565,6 +581,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       // demapper
       c32 carrier;
       det_sincosf(pll_phase, &carrier.im, &carrier.re);  // gr_expj(d_phase), bit-reproducible form
+      carrier = mk(f32_uniform(carrier.re), f32_uniform(carrier.im));  // (the same in every lane: scalar registers)
       float are = 0.f, aim = 0.f;
       const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
