@@ -204,6 +204,25 @@ struct FftTwTable {
     return tw[k * q * (N / (LS * R))];
   }
 };
+// the forward table copied to LDS in the padded layout of the data (index i at i + i/8): for a kernel that runs many
+// transforms per wave and has no registers to spare -- a short LDS read per twiddle instead of a global load whose
+// wait (the vector-memory counter is in order) also waits for everything else the wave has in flight
+struct FftTwLds {
+  const c32* tw;  // LDS, fft_tw_lds_points(N) entries
+  template <int N, int LS, int R, bool INV>
+  __device__ __forceinline__ c32 get(int k, int q) const {
+    c32 w = tw[lpad(k * q * (N / (LS * R)))];
+    if (INV) w.im = -w.im;
+    return w;
+  }
+  template <int N, int LS, int R>
+  __device__ __forceinline__ c32 fwd(int k, int q) const {
+    return tw[lpad(k * q * (N / (LS * R)))];
+  }
+};
+// entries of the forward table the passes of an N-point transform read: indices 0 .. 7*(N/8 - 1)
+__host__ __device__ constexpr int fft_tw_used(int n) { return 7 * (n / 8 - 1) + 1; }
+__host__ __device__ constexpr int fft_tw_lds_points(int n) { return fft_tw_used(n) + fft_tw_used(n) / 8 + 1; }
 template <int N>
 struct FftTwRegs {
   static constexpr int LOG = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : (N == 512) ? 9 : 10;

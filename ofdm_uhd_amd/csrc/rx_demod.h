@@ -173,9 +173,11 @@ struct DemodParams {
 // the |Y[i]-Y[i+2]|^2 scratch of the preamble) | hinv[occ] | dfe[occ] | constellation | reduction scratch (more than
 // one wave only) | the bits of one OFDM symbol | slicer grid (grid constellations only) | the sink's carrier map
 __host__ __device__ inline int demod_symbits_words(int nmap, int nbits) { return (nmap * nbits + 8 + 31) / 32 + 2; }
-// hinv doubles as the correlator scratch (occ + 2*shift + 1 floats) where the transform has one buffer
+// Up to N = 1024 the transform works in ONE buffer (fft_run1) and the space of the second holds the twiddle table
+// (fft.h FftTwLds).  hinv doubles as the correlator scratch (occ + 2*shift + 1 floats): it is rebuilt right after.
+__host__ __device__ constexpr bool demod_tw_lds(int n) { return !fft_onebuf(n); }
 __host__ __device__ inline int demod_hinv_len(int n, int occ, int shift) {
-  const int need = fft_onebuf(n) ? (occ + 2 * shift + 2 + 1) / 2 : 0;
+  const int need = (occ + 2 * shift + 2 + 1) / 2;
   return need > occ ? need : occ;
 }
 // reduction scratch: per-wave partials beyond one wave, per-thread terms (sequential sum) below one
@@ -185,7 +187,8 @@ __host__ __device__ inline int demod_red_floats(int n) { return n / 8 == WAVE ? 
 __host__ __device__ constexpr bool demod_smap_lds(int n) { return n / 8 <= WAVE; }
 template <int N>
 __host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int nbits, int shift, bool grid) {
-  return fft_lds_bytes(N) + (demod_hinv_len(N, occ, shift) + occ) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
+  return (fft_lds_points(N) + (demod_tw_lds(N) ? fft_tw_lds_points(N) : 0)) * (int)sizeof(c32) +
+         (demod_hinv_len(N, occ, shift) + occ) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
          demod_red_floats(N) * (int)sizeof(float) + ((demod_symbits_words(nmap, nbits) + 3) & ~3) * 4 +
          (grid ? (int)sizeof(SlicerGrid) : 0) + (demod_smap_lds(N) ? ((nmap * 2 + 3) & ~3) : 0);
 }
@@ -344,10 +347,11 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
   extern __shared__ __align__(16) unsigned char smem[];
   c32* fftbuf = reinterpret_cast<c32*>(smem);
   c32* Ysh = fftbuf;  // the first FFT buffer is free again after the last pass: shifted spectrum, linear
-  c32* hinv = fftbuf + fft_lds_bufs(N) * fft_lds_points(N);
-  // correlator scratch (occ + 2*shift + 1 floats): the second FFT buffer where there is one, else the
-  // equaliser's own array -- it is rebuilt from scratch right after the correlation (block barriers between)
-  float* sd = fft_onebuf(N) ? reinterpret_cast<float*>(hinv) : reinterpret_cast<float*>(fftbuf + fft_lds_points(N));
+  c32* twl = fftbuf + fft_lds_points(N);  // the twiddle table (N <= 1024)
+  c32* hinv = twl + (demod_tw_lds(N) ? fft_tw_lds_points(N) : 0);
+  // correlator scratch (occ + 2*shift + 1 floats): the equaliser's own array -- it is rebuilt from scratch right after
+  // the correlation (block barriers between)
+  float* sd = reinterpret_cast<float*>(hinv);
   c32* dfe = hinv + demod_hinv_len(N, q.occ, q.shift);
   c32* cst = dfe + q.occ;
   float* red = reinterpret_cast<float*>(cst + q.arity);
@@ -383,6 +387,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
     dfe[i] = mk(1.f, 0.f);
   }
   for (int i = t; i < q.arity; i += T) cst[i] = q.constellation[i];
+  if constexpr (demod_tw_lds(N))
+    for (int i = t; i < fft_tw_used(N); i += T) twl[lpad(i)] = q.tw[i];
   if constexpr (demod_smap_lds(N))
     for (int i = t; i < q.nmap; i += T) smapL[i] = q.smap[i];
   if (use_grid)
@@ -474,7 +480,11 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
         for (int m = 0; m < 8; m++) q.tap_sampler[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = e[m];
       }
       // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
-      fft_run<N, false, FftBlockSync, DEMOD_PK>(e, tl, fftbuf, q.tw, FftBlockSync());
+      if constexpr (demod_tw_lds(N)) {
+        fft_run1<N, false, DEMOD_PK, FftBlockSync, FftTwLds>(e, tl, fftbuf, FftTwLds{twl}, FftBlockSync());
+      } else {
+        fft_run<N, false, FftBlockSync, DEMOD_PK>(e, tl, fftbuf, q.tw, FftBlockSync());
+      }
       // the next symbol's samples, in flight during the acquisition / sink half of this one.  (Issued after the
       // transform: its twiddle loads wait on the in-order vector-memory counter, i.e. on everything issued before them.)
       if (k < K) {
