@@ -220,7 +220,12 @@ struct TxGeom {
   static constexpr int SPW = WG / T;
   static constexpr bool ONEBUF = (TX_ONEBUF && T <= WAVE) || fft_onebuf(N);
   static constexpr int SYM_POINTS = (ONEBUF ? 1 : 2) * fft_lds_points(N);  // c32 per symbol
-  static constexpr int lds_bytes() { return SPW * SYM_POINTS * (int)sizeof(c32) + OFDM_MAX_ARITY * (int)sizeof(c32); }
+  // wave-sized symbols read their twiddles from a table in LDS, staged once per workgroup (fft.h FftTwLds)
+  static constexpr bool TW_LDS = ONEBUF && T <= WAVE;
+  static constexpr int TW_POINTS = TW_LDS ? fft_tw_lds_points(N) : 0;
+  static constexpr int lds_bytes() {
+    return (SPW * SYM_POINTS + TW_POINTS) * (int)sizeof(c32) + OFDM_MAX_ARITY * (int)sizeof(c32);
+  }
 };
 
 template <int N>
@@ -264,8 +269,11 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
   // The symbol's slice of the framed packet (nc * nbits bits) is fetched once, as aligned dwords, into the LDS the
   // transform will use later, and the constellation sits in LDS too: each point then costs two LDS reads instead of
   // a chain of three dependent global loads.
-  c32* cst = reinterpret_cast<c32*>(smem_raw) + SPW * TxGeom<N>::SYM_POINTS;  // [arity], shared by the workgroup
+  c32* twl = reinterpret_cast<c32*>(smem_raw) + SPW * TxGeom<N>::SYM_POINTS;  // twiddle table, shared by the workgroup
+  c32* cst = twl + TxGeom<N>::TW_POINTS;                                       // [arity], shared by the workgroup
   for (int i = threadIdx.x; i < p.arity; i += TxGeom<N>::WG) cst[i] = p.constellation[i];
+  if constexpr (TxGeom<N>::TW_LDS)
+    for (int i = threadIdx.x; i < fft_tw_used(N); i += TxGeom<N>::WG) twl[lpad(i)] = p.tw[i];
   uint32_t* mbytes = reinterpret_cast<uint32_t*>(lds);  // this symbol's message bytes (<= N + 8 of them)
   const uint32_t nb = (uint32_t)p.nbits, bmask = (1u << nb) - 1u;
   const uint8_t* msg = framed + framed_off[pkt];
@@ -328,7 +336,9 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
 
   // up to N = 512 a symbol's N/8 threads sit inside one wave: no workgroup barrier in the exchanges
   if constexpr (T <= WAVE) {
-    if constexpr (TxGeom<N>::ONEBUF)
+    if constexpr (TxGeom<N>::TW_LDS)
+      fft_run1<N, true, TX_PK, FftWaveSync, FftTwLds>(e, t, lds, FftTwLds{twl}, FftWaveSync());
+    else if constexpr (TxGeom<N>::ONEBUF)
       fft_run1<N, true, TX_PK, FftWaveSync, FftTwTable>(e, t, lds, FftTwTable{p.tw}, FftWaveSync());
     else
       fft_run<N, true, FftWaveSync, TX_PK>(e, t, lds, p.tw, FftWaveSync());
