@@ -225,9 +225,9 @@ __host__ __device__ constexpr int fft_tw_used(int n) { return 7 * (n / 8 - 1) + 
 __host__ __device__ constexpr int fft_tw_lds_points(int n) { return fft_tw_used(n) + fft_tw_used(n) / 8 + 1; }
 template <int N>
 struct FftTwRegs {
-  static constexpr int LOG = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : (N == 512) ? 9 : 10;
+  static constexpr int LOG = (N == 64) ? 6 : (N == 128) ? 7 : (N == 256) ? 8 : (N == 512) ? 9 : (N == 1024) ? 10 : (N == 2048) ? 11 : 12;
   static constexpr int LS0 = (LOG % 3 == 1) ? 2 : (LOG % 3 == 2) ? 4 : 8;  // sub-length of the first twiddled pass
-  static constexpr int NP = (N == 64) ? 1 : (N == 1024) ? 3 : 2;            // twiddled (radix-8) passes
+  static constexpr int NP = (N == 64) ? 1 : (N >= 1024) ? 3 : 2;            // twiddled (radix-8) passes
   c32 w[NP][7];
   __device__ __forceinline__ void load(const c32* __restrict__ tw, int t) {
     int ls = LS0;
@@ -335,60 +335,65 @@ __device__ __forceinline__ void fft_pass(c32 e[8], int t, const c32* src, c32* d
 // `lds` points at this transform's 2*fft_lds_points(N) c32 scratch.  SYNC() must
 // synchronise the N/8 threads of the transform (block barrier, or nothing but a
 // compiler fence when they are one wave).
-template <int N, bool INV, typename SyncFn, bool PK = false>
-__device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __restrict__ tw, SyncFn sync) {
+template <int N, bool INV, typename SyncFn, bool PK, typename TwFn>
+__device__ __forceinline__ void fft_run_tw(c32 e[8], int t, c32* lds, const TwFn& tw, SyncFn sync) {
   c32* A = lds;
   c32* B = lds + fft_lds_points(N);
   if constexpr (N == 64) {
-    fft_pass<64, 8, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<64, 8, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<64, 8, 8, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<64, 8, 8, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 128) {
-    fft_pass<128, 2, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<128, 2, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<128, 8, 2, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
+    fft_pass_tw<128, 8, 2, INV, false, false, false, SyncFn, TwFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<128, 8, 16, INV, false, true, false, SyncFn, PK>(e, t, B, nullptr, tw, sync);
+    fft_pass_tw<128, 8, 16, INV, false, true, false, SyncFn, TwFn, PK>(e, t, B, nullptr, tw, sync);
   } else if constexpr (N == 256) {
-    fft_pass<256, 4, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<256, 4, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<256, 8, 4, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
+    fft_pass_tw<256, 8, 4, INV, false, false, false, SyncFn, TwFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<256, 8, 32, INV, false, true, false, SyncFn, PK>(e, t, B, nullptr, tw, sync);
+    fft_pass_tw<256, 8, 32, INV, false, true, false, SyncFn, TwFn, PK>(e, t, B, nullptr, tw, sync);
   } else if constexpr (N == 512) {
-    fft_pass<512, 8, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<512, 8, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<512, 8, 8, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
+    fft_pass_tw<512, 8, 8, INV, false, false, false, SyncFn, TwFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<512, 8, 64, INV, false, true, false, SyncFn, PK>(e, t, B, nullptr, tw, sync);
+    fft_pass_tw<512, 8, 64, INV, false, true, false, SyncFn, TwFn, PK>(e, t, B, nullptr, tw, sync);
   } else if constexpr (N == 1024) {
-    fft_pass<1024, 2, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<1024, 2, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<1024, 8, 2, INV, false, false, false, SyncFn, PK>(e, t, A, B, tw, sync);
+    fft_pass_tw<1024, 8, 2, INV, false, false, false, SyncFn, TwFn, PK>(e, t, A, B, tw, sync);
     sync();
-    fft_pass<1024, 8, 16, INV, false, false, false, SyncFn, PK>(e, t, B, A, tw, sync);
+    fft_pass_tw<1024, 8, 16, INV, false, false, false, SyncFn, TwFn, PK>(e, t, B, A, tw, sync);
     sync();
-    fft_pass<1024, 8, 128, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<1024, 8, 128, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else if constexpr (N == 2048) {  // one buffer
     (void)B;
-    fft_pass<2048, 4, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<2048, 4, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<2048, 8, 4, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
+    fft_pass_tw<2048, 8, 4, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<2048, 8, 32, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
+    fft_pass_tw<2048, 8, 32, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<2048, 8, 256, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<2048, 8, 256, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   } else {  // one buffer
     static_assert(N == 4096, "unsupported FFT length");
     (void)B;
-    fft_pass<4096, 8, 1, INV, true, false, false, SyncFn, PK>(e, t, nullptr, A, tw, sync);
+    fft_pass_tw<4096, 8, 1, INV, true, false, false, SyncFn, TwFn, PK>(e, t, nullptr, A, tw, sync);
     sync();
-    fft_pass<4096, 8, 8, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
+    fft_pass_tw<4096, 8, 8, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<4096, 8, 64, INV, false, false, true, SyncFn, PK>(e, t, A, A, tw, sync);
+    fft_pass_tw<4096, 8, 64, INV, false, false, true, SyncFn, TwFn, PK>(e, t, A, A, tw, sync);
     sync();
-    fft_pass<4096, 8, 512, INV, false, true, false, SyncFn, PK>(e, t, A, nullptr, tw, sync);
+    fft_pass_tw<4096, 8, 512, INV, false, true, false, SyncFn, TwFn, PK>(e, t, A, nullptr, tw, sync);
   }
+}
+
+template <int N, bool INV, typename SyncFn, bool PK = false>
+__device__ __forceinline__ void fft_run(c32 e[8], int t, c32* lds, const c32* __restrict__ tw, SyncFn sync) {
+  fft_run_tw<N, INV, SyncFn, PK, FftTwTable>(e, t, lds, FftTwTable{tw}, sync);
 }
 
 // The same transform (same butterflies, same twiddles, same results bit for bit) in ONE LDS buffer of

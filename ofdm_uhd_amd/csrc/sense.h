@@ -55,6 +55,10 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
     mx[m] = 0.0f;  // reset_stats()
   }
   c32* my = lds + (size_t)g * fft_lds_bufs(NS) * fft_lds_points(NS);
+  // a thread keeps its place in its transform for the whole dwell: its twiddles live in registers.  (Fetched per round
+  // they would be global loads whose waits -- the vector-memory counter is in order -- also wait for the prefetch.)
+  FftTwRegs<NS> twr;
+  twr.load(p.tw, t);
   const uint32_t stride = p.nsplit * G;
   // every group of the workgroup runs the same number of rounds (barriers inside fft_run)
   const uint32_t rounds = (p.dwell_delay + stride - 1) / stride;
@@ -81,9 +85,9 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
       for (int m = 0; m < 8; m++) nx[m] = ln ? src[t + m * TPT] : mk(0.f, 0.f);
     }
     if constexpr (TPT <= WAVE) {
-      fft_run<NS, false, FftWaveSync, SENSE_PK>(e, t, my, p.tw, FftWaveSync());
+      fft_run_tw<NS, false, FftWaveSync, SENSE_PK, FftTwRegs<NS>>(e, t, my, twr, FftWaveSync());
     } else {
-      fft_run<NS, false, FftBlockSync, SENSE_PK>(e, t, my, p.tw, FftBlockSync());
+      fft_run_tw<NS, false, FftBlockSync, SENSE_PK, FftTwRegs<NS>>(e, t, my, twr, FftBlockSync());
     }
 #pragma unroll
     for (int m = 0; m < 8; m++) {
