@@ -153,6 +153,7 @@ struct DemodParams {
   const c32* ks;        // [occ]
   const float* kd;      // [occ]
   const int16_t* smap;  // [nmap]
+  int smap_lds;         // the kernel keeps its own copy of the map in LDS
   const c32* constellation;
   const SlicerGrid* grid;  // nullptr: no grid structure (PSK, small tables): search the table
   const uint8_t* invalid;  // [nframes] (tap pass)
@@ -173,24 +174,23 @@ struct DemodParams {
 // the |Y[i]-Y[i+2]|^2 scratch of the preamble) | hinv[occ] | dfe[occ] | constellation | reduction scratch (more than
 // one wave only) | the bits of one OFDM symbol | slicer grid (grid constellations only) | the sink's carrier map
 __host__ __device__ inline int demod_symbits_words(int nmap, int nbits) { return (nmap * nbits + 8 + 31) / 32 + 2; }
-// Up to N = 1024 the transform works in ONE buffer (fft_run1) and the space of the second holds the twiddle table
-// (fft.h FftTwLds).  hinv doubles as the correlator scratch (occ + 2*shift + 1 floats): it is rebuilt right after.
-__host__ __device__ constexpr bool demod_tw_lds(int n) { return !fft_onebuf(n); }
+// The transform works in ONE LDS buffer; the twiddle table sits beside it in LDS (fft.h FftTwLds) -- always up to
+// N = 1024, and for longer transforms when that does not cost a workgroup per CU (template parameter TWL, the host
+// decides: launch_demod).  hinv doubles as the correlator scratch (occ + 2*shift + 1 floats): it is rebuilt right after.
 __host__ __device__ inline int demod_hinv_len(int n, int occ, int shift) {
   const int need = (occ + 2 * shift + 2 + 1) / 2;
   return need > occ ? need : occ;
 }
 // reduction scratch: per-wave partials beyond one wave, per-thread terms (sequential sum) below one
 __host__ __device__ inline int demod_red_floats(int n) { return n / 8 == WAVE ? 0 : 64; }
-// The sink's carrier map sits in LDS where a frame is ONE wave's work (nothing else hides a global load's latency
-// there); a multi-wave frame reads it from global memory (at N = 4096 the 4.7 KB would cost the second workgroup per CU).
-__host__ __device__ constexpr bool demod_smap_lds(int n) { return n / 8 <= WAVE; }
-template <int N>
-__host__ __device__ inline int demod_lds_bytes(int occ, int arity, int nmap, int nbits, int shift, bool grid) {
-  return (fft_lds_points(N) + (demod_tw_lds(N) ? fft_tw_lds_points(N) : 0)) * (int)sizeof(c32) +
-         (demod_hinv_len(N, occ, shift) + occ) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
-         demod_red_floats(N) * (int)sizeof(float) + ((demod_symbits_words(nmap, nbits) + 3) & ~3) * 4 +
-         (grid ? (int)sizeof(SlicerGrid) : 0) + (demod_smap_lds(N) ? ((nmap * 2 + 3) & ~3) : 0);
+// The sink's carrier map is read once per carrier and symbol: in LDS too, unless that costs a workgroup per CU
+// (DemodParams::smap_lds, the host decides).
+__host__ __device__ inline int demod_lds_bytes(int n, bool twl, bool smap_lds, int occ, int arity, int nmap, int nbits, int shift,
+                                               bool grid) {
+  return (fft_lds_points(n) + (twl ? fft_tw_lds_points(n) : 0)) * (int)sizeof(c32) +
+         (demod_hinv_len(n, occ, shift) + occ) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
+         demod_red_floats(n) * (int)sizeof(float) + ((demod_symbits_words(nmap, nbits) + 3) & ~3) * 4 +
+         (grid ? (int)sizeof(SlicerGrid) : 0) + (smap_lds ? ((nmap * 2 + 3) & ~3) : 0);
 }
 
 // Two wave-wide sums in the normative order (oracle: lane_tree_sum -- partner = lane ^ d for d = 32, 16, ... 1, each
@@ -341,14 +341,15 @@ __device__ __noinline__ dc dexpj(double ph) {
 #ifndef DEMOD_WAVES
 #define DEMOD_WAVES 3  // waves per SIMD the register allocation aims at (measured best of 2 / 3 / 4)
 #endif
-template <int N>
+template <int N, bool TWL>
 __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_demod(DemodParams q) {
+  static_assert(TWL || fft_onebuf(N), "up to N = 1024 the twiddles are always in LDS");
   constexpr int T = N / 8;
   extern __shared__ __align__(16) unsigned char smem[];
   c32* fftbuf = reinterpret_cast<c32*>(smem);
   c32* Ysh = fftbuf;  // the first FFT buffer is free again after the last pass: shifted spectrum, linear
   c32* twl = fftbuf + fft_lds_points(N);  // the twiddle table (N <= 1024)
-  c32* hinv = twl + (demod_tw_lds(N) ? fft_tw_lds_points(N) : 0);
+  c32* hinv = twl + (TWL ? fft_tw_lds_points(N) : 0);
   // correlator scratch (occ + 2*shift + 1 floats): the equaliser's own array -- it is rebuilt from scratch right after
   // the correlation (block barriers between)
   float* sd = reinterpret_cast<float*>(hinv);
@@ -387,9 +388,9 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
     dfe[i] = mk(1.f, 0.f);
   }
   for (int i = t; i < q.arity; i += T) cst[i] = q.constellation[i];
-  if constexpr (demod_tw_lds(N))
+  if constexpr (TWL)
     for (int i = t; i < fft_tw_used(N); i += T) twl[lpad(i)] = q.tw[i];
-  if constexpr (demod_smap_lds(N))
+  if (q.smap_lds)
     for (int i = t; i < q.nmap; i += T) smapL[i] = q.smap[i];
   if (use_grid)
     for (int i = t; i < (int)(sizeof(SlicerGrid) / 4); i += T)
@@ -480,8 +481,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
         for (int m = 0; m < 8; m++) q.tap_sampler[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = e[m];
       }
       // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
-      if constexpr (demod_tw_lds(N)) {
+      if constexpr (!fft_onebuf(N)) {
         fft_run1<N, false, DEMOD_PK, FftBlockSync, FftTwLds>(e, tl, fftbuf, FftTwLds{twl}, FftBlockSync());
+      } else if constexpr (TWL) {
+        fft_run_tw<N, false, FftBlockSync, DEMOD_PK, FftTwLds>(e, tl, fftbuf, FftTwLds{twl}, FftBlockSync());
       } else {
         fft_run<N, false, FftBlockSync, DEMOD_PK>(e, tl, fftbuf, q.tw, FftBlockSync());
       }
@@ -595,7 +598,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       float are = 0.f, aim = 0.f;
       const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
-        const int i = demod_smap_lds(N) ? smapL[c] : q.smap[c];
+        const int i = q.smap_lds ? smapL[c] : q.smap[c];
         const int yi = i + q.zl + coarse;
         const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
         const c32 in = cmul(cmul(hinv[i], comp), Y);
