@@ -221,7 +221,10 @@ struct TxGeom {
   static constexpr bool ONEBUF = (TX_ONEBUF && T <= WAVE) || fft_onebuf(N);
   static constexpr int SYM_POINTS = (ONEBUF ? 1 : 2) * fft_lds_points(N);  // c32 per symbol
   // wave-sized symbols read their twiddles from a table in LDS, staged once per workgroup (fft.h FftTwLds)
-  static constexpr bool TW_LDS = ONEBUF && T <= WAVE;
+#ifndef TX_TW_LDS_BIG
+#define TX_TW_LDS_BIG 1
+#endif
+  static constexpr bool TW_LDS = ONEBUF && (T <= WAVE || TX_TW_LDS_BIG);
   static constexpr int TW_POINTS = TW_LDS ? fft_tw_lds_points(N) : 0;
   static constexpr int lds_bytes() {
     return (SPW * SYM_POINTS + TW_POINTS) * (int)sizeof(c32) + OFDM_MAX_ARITY * (int)sizeof(c32);
@@ -343,7 +346,10 @@ __global__ void __launch_bounds__(TxGeom<N>::WG)
     else
       fft_run<N, true, FftWaveSync, TX_PK>(e, t, lds, p.tw, FftWaveSync());
   } else {
-    fft_run<N, true, FftBlockSync, TX_PK>(e, t, lds, p.tw, FftBlockSync());
+    if constexpr (TxGeom<N>::TW_LDS)
+      fft_run_tw<N, true, FftBlockSync, TX_PK, FftTwLds>(e, t, lds, FftTwLds{twl}, FftBlockSync());
+    else
+      fft_run<N, true, FftBlockSync, TX_PK>(e, t, lds, p.tw, FftBlockSync());
   }
 
   if (!active) return;
