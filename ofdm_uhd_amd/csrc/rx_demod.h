@@ -537,7 +537,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
             index = i0 + 1;
           }
         }
-        coarse = index - q.zl;
+        coarse = __builtin_amdgcn_readfirstlane(index - q.zl);  // (the same in every lane, like the PLL state below)
         // calculate_equalizer()
         {
           const double a = -6.283185307179586476925 * (double)coarse * (double)q.CP / (double)N * 1.0;
@@ -658,6 +658,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       pll_phase = pll_phase + pll_freq - q.phase_gain * angle;
       if (pll_phase >= 6.28318530717958647692f) pll_phase -= 6.28318530717958647692f;
       if (pll_phase < 0.0f) pll_phase += 6.28318530717958647692f;
+      pll_phase = f32_uniform(pll_phase);
+      pll_freq = f32_uniform(pll_freq);
       __syncthreads();  // sbits complete for this symbol
       // ---- bytes of this symbol: header parse, message bytes to the raw slot -----------------------
       const uint32_t byte0 = nbits_total >> 3;                           // index of the byte at sbits bit 0
@@ -667,7 +669,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, DEMOD_WAVES) k_rx_d
       const uint8_t* sb8 = reinterpret_cast<const uint8_t*>(sbits);
       // header bytes (the first four of the frame) are assembled MSB first
       for (uint32_t b = byte0; b < nbytes && b < 4; b++) {
-        hdr = (hdr << 8) | sb8[b - byte0];
+        hdr = (uint32_t)__builtin_amdgcn_readfirstlane((int)((hdr << 8) | sb8[b - byte0]));
         hdr_bytes++;
       }
       if (sstate == 1 && hdr_bytes == 4) {
