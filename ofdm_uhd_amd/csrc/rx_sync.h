@@ -199,7 +199,7 @@ __host__ __device__ inline SyncLds sync_lds_layout(int R, int HM) {
   l.mh = o;  // M history: the CP values before the tile
   o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
   l.misc = o;
-  o += 256;
+  o += 384;
   l.total = o;
   return l;
 }
@@ -512,6 +512,43 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
 #else
 #define SYNC_ABLATE(p, bit) 0
 #endif
+// Thread 0 puts the waves' parts of a tile's detector summary together (see the end of k_sync's tile loop): either the
+// float32 summary of a tile without candidates, or the record k_sync_exact works from.
+__device__ __forceinline__ void sync_finish_tile(const SyncParams& p, const float* slots, uint64_t tile) {
+  constexpr int NW = SYNC_THREADS / WAVE;
+  const float* sl = slots + (int)(tile & 1u) * NW * 6;
+  int w0 = -1, w1 = -1;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    if (reinterpret_cast<const int*>(sl + 6 * w)[4] >= 0) {
+      if (w0 < 0) w0 = w;
+      w1 = w;
+    }
+  }
+  if (w0 < 0) {
+    float tb = sl[0];
+    if (NW == 4) tb = (sl[0] + sl[6]) + (sl[12] + sl[18]);
+    else if (NW == 2) tb = sl[0] + sl[6];
+    p.tile_B[tile] = (double)tb;
+    p.tile_npieces[tile] = 0;
+    return;
+  }
+  float ga = 0.f, gb = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    ga += (w < w0) ? sl[6 * w] : (w == w0) ? sl[6 * w + 1] : 0.0f;
+    gb += (w > w1) ? sl[6 * w] : (w == w1) ? sl[6 * w + 2] : 0.0f;
+  }
+  const unsigned long long r = atomicAdd(p.rec_count, 1ull);  // (capacity: one record per tile)
+  SyncRec rec;
+  rec.tile = tile;
+  rec.amin = reinterpret_cast<const int*>(sl + 6 * w0)[3];
+  rec.bmax = reinterpret_cast<const int*>(sl + 6 * w1)[4];
+  rec.gpre = ga;
+  rec.gpost = gb;
+  p.recs[r] = rec;
+}
+
 // W: workgroups per CU the register allocation aims at -- 3 when the LDS footprint allows three, else 2 (long
 // symbols: the y history alone is N+CP samples).
 // STATIC (history no longer than a tile: N <= 1024 at the usual prefix lengths): the LDS holds [history | tile] at fixed
@@ -534,8 +571,6 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   unsigned char* misc = smem + L.misc;
   float* scA = reinterpret_cast<float*>(misc);                 // 24 floats
   float* scB = reinterpret_cast<float*>(misc + 96);            // 8 floats
-  float* scC = reinterpret_cast<float*>(misc + 128);           // 4 floats
-  int* rng = reinterpret_cast<int*>(misc + 144);               // [0] amin, [1] bmax
 
   const uint64_t seg = blockIdx.x;
   const uint64_t tile_own0 = seg * (uint64_t)p.tiles_per_seg;
@@ -556,6 +591,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   // weight of this thread's 8 samples in the tile summary of the detector average
   const float decay_f = (float)p.decay;
   const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
+  float* slots = reinterpret_cast<float*>(misc + 160);  // [2 tile parities][waves][6]: the waves' parts of a tile summary
+  bool pend = false;       // a tile's summary waits to be put together (uniform)
+  uint64_t pend_tile = 0;
   int rbase = STATIC ? R - SYNC_TILE : 0;  // the slot of the tile's first sample
   auto RW = [R](int s_) { return STATIC ? s_ : ring_wrap(s_, R); };
   // the next tile of y, fetched a tile ahead: its HBM latency hides behind the metric phase
@@ -612,6 +650,10 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     STAMP(1);
     __syncthreads();  // B2: the tile's y is in the ring
     STAMP(2);
+    if (pend) {  // the previous tile's summary: every wave wrote its slot before this barrier
+      if (tid == 0) sync_finish_tile(p, slots, pend_tile);
+      pend = false;
+    }
     const int ybs = RW(rbase + SYNC_V * tl);
     const int yb = sync_lp(ybs), yb1 = sync_lp(RW(ybs - D)), yb2 = sync_lp(RW(RW(ybs - D) - D));
 
@@ -787,71 +829,53 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       wgt = (float)pow(p.decay, (double)(after > 0 ? after : 0));
     }
     if (p.exact_all) amask = (1u << nv) - 1u;
+    // Each WAVE leaves its part of the tile's summary in an LDS slot and moves on -- no workgroup barrier here; thread 0
+    // puts the parts together after the next barrier the loop meets anyway (B2 of the next tile, or the one after the
+    // loop).  A wave's part: the weighted sum S of its samples; whether it saw a candidate; and if so the first / last
+    // candidate position and the sums of its samples before the first (Pre) / after the last (Post).  The tile's range
+    // is [first of the first such wave, last of the last], the float32 summary before it S of the earlier waves + Pre,
+    // after it Post + S of the later waves -- added in wave order, the same additions as a block-wide scan would do.
     {
-      const float bw = wave_incl_scan1_f32(floc * wgt);
-      if (lane_id() == WAVE - 1) scC[wave_id()] = bw;
-    }
-    const int anyc = __syncthreads_or(amask != 0);  // B6
-    STAMP(7);
-    if (tl == 0 && !anyc) {
-      float tb = scC[0];
-      if (SYNC_THREADS / WAVE == 4) tb = (scC[0] + scC[1]) + (scC[2] + scC[3]);
-      else if (SYNC_THREADS / WAVE == 2) tb = scC[0] + scC[1];
-      p.tile_B[tile] = (double)tb;
-      p.tile_npieces[tile] = 0;
-    }
-    if (!anyc) continue;  // (a tile with candidates gets its summary below, from the exact values)
-
-    // ================= something near the threshold in this tile: leave a record for k_sync_exact ============
-    // The fixed-point re-evaluation of the range [amin, bmax], the candidate pieces and the tile's detector summary
-    // are k_sync_exact's work (one workgroup per record, all records in parallel); this kernel only adds what it
-    // alone knows: the float32 summary of the samples before and after the range, weighted to the tile's end.
-    if (tl == 0) {
-      rng[0] = T;
-      rng[1] = -1;
-    }
-    __syncthreads();
-    if (amask) {
-      atomicMin(&rng[0], SYNC_V * tl + __ffs(amask) - 1);
-      atomicMax(&rng[1], SYNC_V * tl + 31 - __clz(amask));
-    }
-    __syncthreads();
-    const int amin = rng[0], bmax = rng[1];
-    float fpre = 0.f, fpost = 0.f;
+      float sw = wave_incl_scan1_f32(floc * wgt);
+      const unsigned long long cb = __ballot(amask != 0);
+      int amin_w = T, bmax_w = -1;
+      float pre_w = 0.f, post_w = 0.f;
+      if (cb != 0ull) {  // (wave-uniform)
+        const int l0 = __ffsll((long long)cb) - 1, l1 = 63 - __clzll((long long)cb);
+        const unsigned m0 = (unsigned)__builtin_amdgcn_readlane((int)amask, l0);
+        const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)amask, l1);
+        const int wbase_l = tl - lane_id();  // first thread of this wave
+        amin_w = SYNC_V * (wbase_l + l0) + __ffs((int)m0) - 1;
+        bmax_w = SYNC_V * (wbase_l + l1) + 31 - __clz((int)m1);
+        float fpre = 0.f, fpost = 0.f;
 #pragma unroll
-    for (int j = 0; j < SYNC_V; j++) {
-      if (j < nv) {
-        const int i = SYNC_V * tl + j;
-        fpre = fmaf(fpre, decay_f, p.alpha * ((i < amin) ? u[j] : 0.0f));
-        fpost = fmaf(fpost, decay_f, p.alpha * ((i > bmax) ? u[j] : 0.0f));
+        for (int j = 0; j < SYNC_V; j++) {
+          if (j < nv) {
+            const int i = SYNC_V * tl + j;
+            fpre = fmaf(fpre, decay_f, p.alpha * ((i < amin_w) ? u[j] : 0.0f));
+            fpost = fmaf(fpost, decay_f, p.alpha * ((i > bmax_w) ? u[j] : 0.0f));
+          }
+        }
+        pre_w = fpre * wgt;
+        post_w = fpost * wgt;
+        wave_incl_scan2_f32(pre_w, post_w);
       }
-    }
-    {
-      float a = fpre * wgt, b = fpost * wgt;
-      wave_incl_scan2_f32(a, b);
       if (lane_id() == WAVE - 1) {
-        scA[2 * wave_id()] = a;
-        scA[2 * wave_id() + 1] = b;
+        float* sl = slots + ((int)(tile & 1u) * (SYNC_THREADS / WAVE) + wave_id()) * 6;
+        sl[0] = sw;
+        sl[1] = pre_w;
+        sl[2] = post_w;
+        reinterpret_cast<int*>(sl)[3] = amin_w;
+        reinterpret_cast<int*>(sl)[4] = bmax_w;
       }
     }
+    pend = true;
+    pend_tile = tile;
+    STAMP(7);
+  }
+  if (pend) {
     __syncthreads();
-    if (tl == 0) {
-      float ga = 0.f, gb = 0.f;
-#pragma unroll
-      for (int w = 0; w < SYNC_THREADS / WAVE; w++) {
-        ga += scA[2 * w];
-        gb += scA[2 * w + 1];
-      }
-      const unsigned long long r = atomicAdd(p.rec_count, 1ull);  // (capacity: one record per tile)
-      SyncRec rec;
-      rec.tile = tile;
-      rec.amin = amin;
-      rec.bmax = bmax;
-      rec.gpre = ga;
-      rec.gpost = gb;
-      p.recs[r] = rec;
-    }
-    STAMP(8);
+    if (tid == 0) sync_finish_tile(p, slots, pend_tile);
   }
 #ifdef SYNC_STAMPS
   if (p.stamps && threadIdx.x == 0)
