@@ -403,7 +403,7 @@ __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scra
 // Rare path (only where the float32 pre-selection found something): kept out of line so that it
 // does not weigh on the register allocation of the streaming loop.
 // ---------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool KEEP>
 __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, float* me, float* ue, c32* gP, float* gU, long long* sc_i64,
                                                  int amin, int bmax, int D, int CP, int64_t t0s, int64_t qvalid, int64_t mvalid,
                                                  float tapcp) {
@@ -436,23 +436,48 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
   // (ii) per-thread chunk of the delta sequence, scan, exact M
   const int lc = (n_e + NT - 1) / NT;
   const int k0 = tid * lc, k1 = (k0 + lc < n_e) ? (k0 + lc) : n_e;
+  // A thread's deltas (new term minus the term leaving the window) are needed twice -- for its chunk total before the
+  // scan and again, one by one, after it.  Chunks of up to EXACT_KEEP samples keep them in registers between the two
+  // passes; longer chunks evaluate them again.  KEEP is a template parameter because the 60 registers cost residency:
+  // measured, it pays at N = 4096 (k_sync_exact 1.20 -> 0.89 ms at C5) and loses at N = 2048 / 512 (0.58 -> 0.63,
+  // 0.63 -> 0.69 ms): the host turns it on for D >= 2048.
+  constexpr int EXACT_KEEP = KEEP ? 10 : 1;
+  const bool keep = KEEP && lc <= EXACT_KEEP;
+  Q3 dq[EXACT_KEEP];
   Q3 tq = {0, 0, 0};
-  for (int k = k0; k < k1; k++) {
-    const int m = s0 + 1 + k;
-    const Q3 a = QTERM(m), b = QTERM(m - D);
-    tq.pr += a.pr - b.pr;
-    tq.pi += a.pi - b.pi;
-    tq.r += a.r - b.r;
+  if (keep) {
+#pragma unroll
+    for (int i = 0; i < EXACT_KEEP; i++) {
+      Q3 d = {0, 0, 0};
+      if (k0 + i < k1) {
+        const int m = s0 + 1 + k0 + i;
+        const Q3 a = QTERM(m), b = QTERM(m - D);
+        d.pr = a.pr - b.pr;
+        d.pi = a.pi - b.pi;
+        d.r = a.r - b.r;
+      }
+      dq[i] = d;
+      tq.pr += d.pr;
+      tq.pi += d.pi;
+      tq.r += d.r;
+    }
+  } else {
+    for (int k = k0; k < k1; k++) {
+      const int m = s0 + 1 + k;
+      const Q3 a = QTERM(m), b = QTERM(m - D);
+      tq.pr += a.pr - b.pr;
+      tq.pi += a.pi - b.pi;
+      tq.r += a.r - b.r;
+    }
   }
   Q3 ex, ansum;
   block_scan3_sum3_i64<NT>(tq, an, sc_i64, &ex, &ansum);
   long long wpr = ansum.pr + ex.pr, wpi = ansum.pi + ex.pi, wr = ansum.r + ex.r;
-  for (int k = k0; k < k1; k++) {
+  auto emit = [&](int k, Q3 d) {
     const int m = s0 + 1 + k;
-    const Q3 a = QTERM(m), b = QTERM(m - D);
-    wpr += a.pr - b.pr;
-    wpi += a.pi - b.pi;
-    wr += a.r - b.r;
+    wpr += d.pr;
+    wpi += d.pi;
+    wr += d.r;
     const float pre = (float)q40_to_double(wpr);
     const float pim = (float)q40_to_double(wpi);
     const float r = (float)q40_to_double(wr);
@@ -463,6 +488,21 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
     if (t0s + m < mvalid) mm = 0.0f;
     me[k] = mm;
     if (m >= amin) gP[m - amin] = mk(pre, pim);
+  };
+  if (keep) {
+#pragma unroll
+    for (int i = 0; i < EXACT_KEEP; i++)
+      if (k0 + i < k1) emit(k0 + i, dq[i]);
+  } else {
+    for (int k = k0; k < k1; k++) {
+      const int m = s0 + 1 + k;
+      const Q3 a = QTERM(m), b = QTERM(m - D);
+      Q3 d;
+      d.pr = a.pr - b.pr;
+      d.pi = a.pi - b.pi;
+      d.r = a.r - b.r;
+      emit(k, d);
+    }
   }
   __syncthreads();
   // (iii) exact CP-length moving sum of M over [amin, bmax]; me[k] holds sample s0+1+k = amin-CP+1+k
@@ -904,7 +944,7 @@ __host__ __device__ inline int sync_exact_small(int CP, int D) {
   const int r = 2 * CP + 768;
   return r > SYNC_TILE ? SYNC_TILE : r;
 }
-template <int NT>
+template <int NT, bool KEEP>
 __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int T = SYNC_TILE;
@@ -954,7 +994,7 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
     cand_base += (unsigned long long)rlen;
     cand_left -= (uint32_t)rlen;
     if (fits) {
-      sync_exact_range<NT>(p.y, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, t0s, qvalid, mvalid, p.tapcp);
+      sync_exact_range<NT, KEEP>(p.y, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, t0s, qvalid, mvalid, p.tapcp);
     } else {
       for (int i = tl; i < rlen; i += NT) ue[i] = -1.0f;  // nothing can be stored: no candidates
       __syncthreads();
