@@ -341,13 +341,16 @@ __device__ __noinline__ dc dexpj(double ph) {
 #ifndef DEMOD_WAVES
 #define DEMOD_WAVES 3  // waves per SIMD the register allocation aims at (measured best of 2 / 3 / 4)
 #endif
-// A 512-thread frame (N = 4096) gets the 128-register budget: two workgroups per CU instead of one (3.9 -> 2.9 ms at
-// C5, spills and all -- and the LDS then has no room for the twiddle table or the carrier map, see launch_demod).
+// Frames of four waves and more (N >= 2048) get the 128-register budget: one more workgroup per CU, spills and all
+// (C5: 3.9 -> 2.95 ms with two workgroups instead of one; C3: 2.30 -> 2.05 ms with four instead of three) -- the LDS
+// then has no room for the twiddle table or the carrier map, see launch_demod.  A one-wave frame (N = 512) stays at
+// 168 registers: its LDS admits twelve workgroups per CU either way.
 #ifndef DEMOD_WAVES_BIG
 #define DEMOD_WAVES_BIG 4
 #endif
+__host__ __device__ constexpr int demod_waves_per_simd(int n) { return (n / 8 >= 256) ? DEMOD_WAVES_BIG : DEMOD_WAVES; }
 template <int N, bool TWL>
-__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, (N / 8 >= 512) ? DEMOD_WAVES_BIG : DEMOD_WAVES) k_rx_demod(DemodParams q) {
+__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_simd(N)) k_rx_demod(DemodParams q) {
   static_assert(TWL || fft_onebuf(N), "up to N = 1024 the twiddles are always in LDS");
   constexpr int T = N / 8;
   extern __shared__ __align__(16) unsigned char smem[];
