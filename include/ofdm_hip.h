@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OFDM_ABI_VERSION 4
+#define OFDM_ABI_VERSION 5
 
 #define OFDM_MAX_FFT 4096
 #define OFDM_MAX_CARRIER_HEX 1024 /* hex digits of a carrier map: OFDM_MAX_FFT / 4 */
@@ -84,7 +84,7 @@ typedef struct ofdm_cfg {
 
   float peak_rise;  /* gr_peak_detector_fb threshold_factor_rise 0.20 (ofdm_sync_pn) */
   float peak_fall;  /* gr_peak_detector_fb threshold_factor_fall 0.20 */
-  float peak_alpha; /* gr_peak_detector_fb alpha 0.001 */
+  float peak_alpha; /* gr_peak_detector_fb alpha 0.001; accepted range (0, 0.25] */
 
   uint32_t ntaps;             /* len(chan_coeffs), odd (ofdm_receiver.py~:71-75) */
   float taps[OFDM_MAX_TAPS];  /* gr.firdes.low_pass(1, 1, bw+tb, tb, WIN_HAMMING) as float32 */
@@ -311,7 +311,10 @@ enum {
   OFDM_TAP_RX_SAMPLER = 13,  /* c32[nsym][N]: ofdm_receiver-sampler_c.dat (the sampled, derotated symbols = FFT input) */
   OFDM_TAP_RX_SIGMIX = 14,   /* c32[nsamples]: ofdm_receiver-sigmix_c.dat (chan_filt * nco, whole stream)  */
   OFDM_TAP_RX_NCO = 15,      /* c32[nsamples]: ofdm_receiver-nco_c.dat (frequency_modulator_fc output)     */
-  OFDM_TAP_COUNT = 16
+  OFDM_TAP_RX_PRESEL = 16,   /* f32[nsamples]: the float32 pre-selection of the timing metric (engine-internal stage, DESIGN.md
+                              * section 2: it picks the ranges the normative metric is evaluated on and feeds the peak
+                              * detector's running average outside them); no reference probe point */
+  OFDM_TAP_COUNT = 17
 };
 /* SIGMIX / NCO evaluate the NCO's closed form sample by sample over the whole stream; inside the symbols the
  * sampler picks, the receiver itself advances the same phasor by a float64 recurrence: RX_SAMPLER is

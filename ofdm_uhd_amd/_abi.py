@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"`` or ``make -C ofdm_uhd_amd/csrc``).
 import ctypes as C
 import os
 
-OFDM_ABI_VERSION = 4
+OFDM_ABI_VERSION = 5
 OFDM_MAX_FFT = 4096
 OFDM_MAX_TAPS = 512
 OFDM_MAX_ARITY = 256
@@ -27,7 +27,7 @@ OFDM_F_PAD_FOR_USRP = 1 << 1
 
 (TAP_TX_PACKETS, TAP_TX_FREQ, TAP_RX_CHAN_FILT, TAP_RX_METRIC, TAP_RX_PEAKS, TAP_RX_ANGLES,
  TAP_RX_FRAMES, TAP_RX_FFT, TAP_RX_ACQ, TAP_RX_SINK, TAP_RX_PACKETS, TAP_TX_MAPPER, TAP_TX_IFFT, TAP_RX_SAMPLER,
- TAP_RX_SIGMIX, TAP_RX_NCO, TAP_COUNT) = range(17)
+ TAP_RX_SIGMIX, TAP_RX_NCO, TAP_RX_PRESEL, TAP_COUNT) = range(18)
 SYNC_PN, SYNC_FIXED = 0, 1
 
 (K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_EXACT, K_COUNT) = range(11)

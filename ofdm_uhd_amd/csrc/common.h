@@ -108,6 +108,12 @@ __device__ __forceinline__ long long q40_from_float(float v) {
   long long b = __double_as_longlong(t);
   return (b & 0x000FFFFFFFFFFFFFll) - 0x0008000000000000ll;
 }
+// llrint(x * 2^40) of a float64 |x| < 2048 (the scaling is exact; the addition rounds to nearest even)
+__device__ __forceinline__ long long q40_from_double(double x) {
+  double t = x * Q40_SCALE + 6755399441055744.0;  // 1.5 * 2^52
+  long long b = __double_as_longlong(t);
+  return (b & 0x000FFFFFFFFFFFFFll) - 0x0008000000000000ll;
+}
 __device__ __forceinline__ long long q40_clamped(float v) {
   v = fminf(fmaxf(v, -511.0f), 511.0f);
   return q40_from_float(v);

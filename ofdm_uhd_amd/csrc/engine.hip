@@ -65,7 +65,7 @@ struct ofdm_handle {
   std::string err;
 
   // constant tables
-  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_Hf, d_twF, d_ks, d_smap, d_kd, d_xp8, d_grid;
+  DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_Hf, d_twF, d_ks, d_smap, d_kd, d_xp8, d_grid, d_synctab;
   bool has_grid = false;  // the constellation is a full grid of levels (QAM tables): constant-time slicer
   int filtF = 0;  // transform length of the channel filter (sync_filter_F)
 
@@ -263,8 +263,9 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   if (cfg->arity < 2 || cfg->arity > OFDM_MAX_ARITY) FAIL(h, OFDM_E_INVAL, "arity must be in [2, 256]");
   if (cfg->ntaps < 1 || cfg->ntaps > OFDM_MAX_TAPS) FAIL(h, OFDM_E_INVAL, "ntaps must be in [1, 512]");
   if (cfg->whitener_offset > 15) FAIL(h, OFDM_E_INVAL, "whitener_offset must be between 0 and 15, inclusive");
-  if (!(cfg->peak_rise > 0.f) || !(cfg->peak_fall > 0.f) || !(cfg->peak_alpha > 0.f) || !(cfg->peak_alpha < 1.f))
-    FAIL(h, OFDM_E_INVAL, "peak detector factors must be positive, alpha in (0,1)");
+  // (alpha <= 0.25: the closed form of the detector's running average carries weights decay^-2048 in float64)
+  if (!(cfg->peak_rise > 0.f) || !(cfg->peak_fall > 0.f) || !(cfg->peak_alpha > 0.f) || !(cfg->peak_alpha <= 0.25f))
+    FAIL(h, OFDM_E_INVAL, "peak detector factors must be positive, alpha in (0, 0.25]");
   if (cfg->max_fft_shift_len > 64) FAIL(h, OFDM_E_INVAL, "max_fft_shift_len too large");
   if (cfg->sync_mode != OFDM_SYNC_PN && cfg->sync_mode != OFDM_SYNC_FIXED)
     FAIL(h, OFDM_E_INVAL, "sync_mode must be OFDM_SYNC_PN or OFDM_SYNC_FIXED (\"ml\" / \"pnac\" need blocks the reference does not ship)");
@@ -396,6 +397,20 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
     }
     HIPCHK(h, upload(h->d_xp8, xp8.data(), xp8.size()));
   }
+  {
+    // tables of the peak detector's normative average (rx_sync.h SyncParams; the oracle builds the same ones):
+    // dpow[j] = decay^j by repeated multiplication | ipow[j] = 1 / dpow[j] | wtab[t] (float)
+    const double decay = (double)(1.0f - cfg->peak_alpha);
+    std::vector<double> tab(2 * (SYNC_TILE + 1) + SYNC_THREADS / 2);
+    double* dp = tab.data();
+    double* ip = dp + (SYNC_TILE + 1);
+    float* wt = reinterpret_cast<float*>(ip + (SYNC_TILE + 1));
+    dp[0] = 1.0;
+    for (int j = 1; j <= SYNC_TILE; j++) dp[j] = dp[j - 1] * decay;
+    for (int j = 0; j <= SYNC_TILE; j++) ip[j] = 1.0 / dp[j];
+    for (int t = 0; t < SYNC_THREADS; t++) wt[t] = (float)dp[SYNC_TILE - SYNC_V * (t + 1)];
+    HIPCHK(h, upload(h->d_synctab, tab.data(), tab.size()));
+  }
   HIPCHK(h, upload(h->d_Hf, Hf.data(), Hf.size()));
   HIPCHK(h, upload(h->d_twF, twF.data(), twF.size()));
   HIPCHK(h, upload(h->d_ks, reinterpret_cast<const c32*>(cfg->known_symbol), (size_t)occ));
@@ -432,7 +447,7 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
   if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
   if (h->own_txs) (void)hipStreamSynchronize(h->own_txs);
   DevBuf* bufs[] = {&h->d_const,    &h->d_preamble,    &h->d_tw,          &h->d_bin2car, &h->d_mask,
-                    &h->d_crc,      &h->d_Hf,   &h->d_twF,     &h->d_grid,    &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
+                    &h->d_crc,      &h->d_Hf,   &h->d_twF,     &h->d_grid,  &h->d_synctab,    &h->d_ks,          &h->d_smap,    &h->d_kd,  &h->d_xp8,
                     &h->d_payloads, &h->d_payload_off, &h->d_payload_len, &h->d_framed,  &h->d_framed_off,
                     &h->d_sym_off,  &h->d_sym_pkt,     &h->d_iq_stage,    &h->d_freq_tap, &h->d_ifft_tap};
   for (DevBuf* b : bufs) b->release();

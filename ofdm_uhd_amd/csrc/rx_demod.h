@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(256) k_sigmix_tap(const c32* __restrict__ y, u
 // receive-side workspaces
 // ------------------------------------------------------------------------------------
 struct RxState {
-  DevBuf recs, x_stage, y, metric, tile_B, tile_np, tile_first, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
+  DevBuf recs, x_stage, y, metric, presel, tile_B, tile_np, tile_first, tile_pieces, avg_in, cand_u, cand_P, counters, counts, offsets,
       partial, peaks, peak_P, angle, step, inc, Phi, K, nsym, sym_base, res, raw, invalid, chain_list, key, pos,
       out_payload, out_off, out_len, out_ok, out_pos, inc_acc, Phi_u, peaks2, peak_P2, fstep, pre_inv, stash_peaks, stash_P, tap_fft, tap_acq, tap_sink, tap_demapped, raw_tap, raw_lens, raw_pos, tap_sampler, tap_sigmix, tap_nco;
   uint64_t nsamples = 0, npeaks = 0, nframes = 0, j0 = 0, nsym_total = 0, raw_tap_bytes = 0;
@@ -997,7 +997,7 @@ struct RxState {
   std::vector<uint8_t> hist_swallowed;
   std::vector<uint8_t> last_swallowed;  // per flag of the last call: its frame was swallowed by an earlier packet
   void release() {
-    DevBuf* all[] = {&recs, &x_stage, &y,      &metric,  &tile_B,   &tile_np,  &tile_first, &tile_pieces, &avg_in,     &cand_u,
+    DevBuf* all[] = {&recs, &x_stage, &y,      &metric,  &presel, &tile_B,   &tile_np,  &tile_first, &tile_pieces, &avg_in,     &cand_u,
                      &cand_P,  &counters, &counts, &offsets,  &partial,  &peaks,       &peak_P,     &angle,
                      &step,    &inc,    &Phi,     &K,        &nsym,     &sym_base,    &res,        &raw,
                      &invalid, &chain_list, &key, &pos,      &out_payload, &out_off,  &out_len,    &out_ok,

@@ -34,6 +34,7 @@
 #define SYNC_V 8                            // consecutive samples per thread
 #define SYNC_TILE (SYNC_THREADS * SYNC_V)   // 2048 samples per tile
 #define SYNC_GUARD 1.0e-3f                  // guard band of the float32 pre-selection
+#define SYNC_ILL 0.015625f                  // window energy below 1/64 of its running maximum: float32 has lost it
 #define SYNC_CHUNK_C 4096                   // candidates per allocation chunk (>= SYNC_TILE)
 #define SYNC_CHUNK_P 1024                   // pieces per allocation chunk (>= SYNC_TILE / 2)
 
@@ -56,8 +57,8 @@ struct SyncParams {
   int HY;         // y history the metric needs before a tile (2*D, multiple of 8)
   int HM;         // M history (CP)
   int R;          // samples in the LDS ring of y (multiple of 8)
-  int tiles_per_seg, nwarm;
-  int exact_all;  // metric tap: evaluate every sample in fixed point
+  int tiles_per_seg;
+  int tap_only;   // k_sync_exact: metric tap pass -- every tile's whole range re-evaluated into metric_tap, nothing else written
   int ablate;     // diagnostic build only (-DSYNC_DIAG, see SYNC_ABLATE): 2 skip metric
   unsigned long long* stamps;  // diagnostic build (-DSYNC_STAMPS): [wg][12] cycles per phase of wave 0
   uint64_t nsamples, ntiles;
@@ -66,7 +67,13 @@ struct SyncParams {
   float alpha;       // peak detector alpha
   double decay;      // double(1.0f - alpha)
   const c32* y;       // filtered stream (k_chan_filter's output)
-  float* metric_tap;  // optional [nsamples]
+  float* metric_tap;  // optional [nsamples]: the normative metric (k_sync_exact's tap pass)
+  float* presel_tap;  // optional [nsamples]: the float32 pre-selection (k_sync)
+  // tables of the normative average (host, create_impl): dpow[j] = decay^j by repeated multiplication, j = 0..SYNC_TILE;
+  // ipow[j] = 1 / dpow[j]; wtab[t] = float(dpow[SYNC_TILE - SYNC_V (t + 1)]): weight of lane t's chain in a full tile
+  const double* dpow;
+  const double* ipow;
+  const float* wtab;
   // outputs
   double* tile_B;          // [ntiles] zero-init running average over the tile
   uint32_t* tile_npieces;  // [ntiles] candidate pieces of the tile ...
@@ -281,6 +288,14 @@ __device__ __forceinline__ void wave_incl_scan2_f32(float& a, float& b) {
                    DPP_STEP2("row_shr:8", "0xf") DPP_STEP2("row_bcast:15", "0xa") DPP_STEP2("row_bcast:31", "0xc")
                : "+v"(a), "+v"(b));
 }
+#define DPP_MAX1(CTRL, MASK) "v_max_f32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\ts_nop 1\n\t"
+// the same network with max instead of add: inclusive running maximum over the lanes of a wave
+__device__ __forceinline__ float wave_incl_scanmax_f32(float a) {
+  asm volatile("s_nop 1\n\t" DPP_MAX1("row_shr:1", "0xf") DPP_MAX1("row_shr:2", "0xf") DPP_MAX1("row_shr:4", "0xf")
+                   DPP_MAX1("row_shr:8", "0xf") DPP_MAX1("row_bcast:15", "0xa") DPP_MAX1("row_bcast:31", "0xc")
+               : "+v"(a));
+  return a;
+}
 #define DPP_STEP1(CTRL, MASK) "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\ts_nop 1\n\t"
 __device__ __forceinline__ float wave_incl_scan1_f32(float a) {
   asm volatile("s_nop 1\n\t" DPP_STEP1("row_shr:1", "0xf") DPP_STEP1("row_shr:2", "0xf") DPP_STEP1("row_shr:4", "0xf")
@@ -405,15 +420,14 @@ __device__ __forceinline__ void block_scan3_sum3_i64(Q3 v, Q3 s, long long* scra
 // ---------------------------------------------------------------------------------
 template <int NT, bool KEEP>
 __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, float* me, float* ue, c32* gP, float* gU, long long* sc_i64,
-                                                 int amin, int bmax, int D, int CP, int64_t t0s, int64_t qvalid, int64_t mvalid,
-                                                 float tapcp) {
+                                                 int amin, int bmax, int D, int CP, int64_t t0s, float tapcp) {
   const int tid = threadIdx.x;
 #define QTERM(m)                                                                   \
   ([&]() -> Q3 {                                                                   \
     Q3 q_ = {0, 0, 0};                                                             \
-    if (t0s + (int64_t)(m) >= qvalid) {                                            \
-      const int64_t ia_ = t0s + (int64_t)(m);   /* y before the stream start reads as zero */ \
-      const c32 a_ = ia_ >= 0 ? y[ia_] : mk(0.f, 0.f);                             \
+    const int64_t ia_ = t0s + (int64_t)(m);   /* y before the stream start reads as zero */ \
+    if (ia_ >= 0) {                                                                \
+      const c32 a_ = y[ia_];                                                       \
       const c32 d_ = ia_ >= D ? y[ia_ - D] : mk(0.f, 0.f);                         \
       const c32 c_ = cmul_conj(a_, d_);                                            \
       q_.pr = q40_clamped(c_.re);                                                  \
@@ -485,9 +499,8 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
     const float den = r * r;
     float mm = (den > 0.0f) ? (num / den) : 0.0f;
     if (!(mm <= 1024.0f)) mm = 1024.0f;
-    if (t0s + m < mvalid) mm = 0.0f;
     me[k] = mm;
-    if (m >= amin) gP[m - amin] = mk(pre, pim);
+    if (gP && m >= amin) gP[m - amin] = mk(pre, pim);
   };
   if (keep) {
 #pragma unroll
@@ -521,7 +534,7 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
     const float mbar = (float)(q40_to_double(wm) * (double)tapcp);
     const float ux = mbar + (-1.0f);
     ue[jj] = ux;
-    gU[jj] = ux;
+    if (gU) gU[jj] = ux;
   }
   __syncthreads();
 #undef QTERM
@@ -553,10 +566,33 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
 #define SYNC_ABLATE(p, bit) 0
 #endif
 // Thread 0 puts the waves' parts of a tile's detector summary together (see the end of k_sync's tile loop): either the
-// float32 summary of a tile without candidates, or the record k_sync_exact works from.
-__device__ __forceinline__ void sync_finish_tile(const SyncParams& p, const float* slots, uint64_t tile) {
+// float32 summary of a tile without candidates, or the record k_sync_exact works from.  A tile in which the float32
+// window energy fell below SYNC_ILL of its running maximum (cancellation: the float32 metric cannot be trusted there) --
+// or whose predecessor did, whose M values its first CP means still average -- is handed over whole.  Returns whether
+// this tile was ill-conditioned.
+__device__ __forceinline__ bool sync_tile_ill(const float* slots, uint64_t tile) {
   constexpr int NW = SYNC_THREADS / WAVE;
   const float* sl = slots + (int)(tile & 1u) * NW * 6;
+  bool ill = false;
+#pragma unroll
+  for (int w = 0; w < NW; w++) ill = ill || reinterpret_cast<const int*>(sl + 6 * w)[5] != 0;
+  return ill;
+}
+__device__ __forceinline__ bool sync_finish_tile(const SyncParams& p, const float* slots, uint64_t tile, bool prev_ill) {
+  constexpr int NW = SYNC_THREADS / WAVE;
+  const float* sl = slots + (int)(tile & 1u) * NW * 6;
+  const bool ill = sync_tile_ill(slots, tile);
+  if (ill || prev_ill) {
+    const uint64_t t0 = tile * (uint64_t)SYNC_TILE;
+    const unsigned long long r = atomicAdd(p.rec_count, 1ull);
+    SyncRec rec;
+    rec.tile = tile;
+    rec.amin = 0;
+    rec.bmax = ((t0 + (uint64_t)SYNC_TILE <= p.nsamples) ? SYNC_TILE : (int)(p.nsamples - t0)) - 1;
+    rec.gpre = rec.gpost = 0.0f;
+    p.recs[r] = rec;
+    return ill;
+  }
   int w0 = -1, w1 = -1;
 #pragma unroll
   for (int w = 0; w < NW; w++) {
@@ -571,7 +607,7 @@ __device__ __forceinline__ void sync_finish_tile(const SyncParams& p, const floa
     else if (NW == 2) tb = sl[0] + sl[6];
     p.tile_B[tile] = (double)tb;
     p.tile_npieces[tile] = 0;
-    return;
+    return ill;
   }
   float ga = 0.f, gb = 0.f;
 #pragma unroll
@@ -587,6 +623,7 @@ __device__ __forceinline__ void sync_finish_tile(const SyncParams& p, const floa
   rec.gpre = ga;
   rec.gpost = gb;
   p.recs[r] = rec;
+  return ill;
 }
 
 // W: workgroups per CU the register allocation aims at -- 3 when the LDS footprint allows three, else 2 (long
@@ -594,6 +631,15 @@ __device__ __forceinline__ void sync_finish_tile(const SyncParams& p, const floa
 // STATIC (history no longer than a tile: N <= 1024 at the usual prefix lengths): the LDS holds [history | tile] at fixed
 // places and the newest R - T samples are copied to the front after each tile's last read -- every LDS address of the
 // tile loop is then one per-thread base plus uniform offsets, where the ring costs a wrap per access.
+//
+// NORMATIVE SCHEDULE.  The float32 values this kernel produces (u of every sample, the per-wave parts of a tile's
+// detector summary) are part of the receiver's defined result: they pick the ranges of the fixed-point evaluation and
+// feed the peak detector's average outside them, so the oracle performs the same operations in the same order
+// (oracle/ofdm_oracle.c, peak_detect: "lanes" = threads, "scan network" = wave_incl_scan*_f32, "groups" = waves).
+// A tile's values depend only on y[t0 - 2D - CP .. t0 + T): window sums anchored afresh at the tile start, the CP
+// values of M before the tile computed by the previous tile's evaluation.  A segment therefore starts one tile early (the
+// warm-up tile: a full evaluation whose M values seed the first owned tile, its u discarded) behind a prologue that
+// loads the 2D samples of history -- any segmentation of the stream gives the same bits.
 template <int W, bool STATIC>
 __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #ifdef SYNC_STAMPS
@@ -616,24 +662,33 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   const uint64_t tile_own0 = seg * (uint64_t)p.tiles_per_seg;
   uint64_t tile_own1 = tile_own0 + (uint64_t)p.tiles_per_seg;
   if (tile_own1 > p.ntiles) tile_own1 = p.ntiles;
-  const bool warm = seg > 0;
-  const uint64_t tile_first = warm ? tile_own0 - (uint64_t)p.nwarm : tile_own0;
-  const uint64_t ws = tile_first * (uint64_t)T;
-  const int64_t qvalid = warm ? (int64_t)(ws + (uint64_t)p.D) : 0;
-  const int64_t mvalid = warm ? (int64_t)(ws + 2ull * (uint64_t)p.D) - 1 : 0;
+  const uint64_t tile_first = seg > 0 ? tile_own0 - 1 : tile_own0;
   const int D = p.D, CP = p.CP, HM = p.HM;
   const float inv_cp = 1.0f / (float)CP;
 
-  // ---- segment prologue: the ring (y before the stream start reads as zero) and the M history ----
-  for (int i = tid; i < sync_lp(R) + 2; i += SYNC_THREADS) ys[i] = mk(0.f, 0.f);
+  // ---- segment prologue: the y history of the first tile walked (y before the stream start reads as zero; so does the
+  //      M history, which only the stream's first tile ever uses: a warm-up tile's u is discarded) ----
+  {
+    const int H = R - T;                                   // history samples in front of a tile (>= 2D)
+    const int64_t h0 = (int64_t)(tile_first * (uint64_t)T) - H;
+    for (int c = tid; c < H; c += SYNC_THREADS) {
+      const int64_t n = h0 + c;
+      const c32 v = n >= 0 ? p.y[n] : mk(0.f, 0.f);          // (n < nsamples: it lies before a tile that exists)
+      ys[sync_lp(STATIC ? c : ring_wrap(c - H, R))] = v;
+    }
+    for (int i = tid; i < 2; i += SYNC_THREADS) ys[sync_lp(R) + i] = mk(0.f, 0.f);
+  }
   for (int i = tid; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = 0.0f;
   const bool y_al16 = ((uintptr_t)p.y & 15) == 0;
   // weight of this thread's 8 samples in the tile summary of the detector average
   const float decay_f = (float)p.decay;
-  const float wfull = (float)pow(p.decay, (double)(T - SYNC_V * (tid + 1)));
+  const float wfull = p.wtab[tid];
   float* slots = reinterpret_cast<float*>(misc + 160);  // [2 tile parities][waves][6]: the waves' parts of a tile summary
   bool pend = false;       // a tile's summary waits to be put together (uniform)
+  bool pend_warm = false;  // the warm-up tile's ill-conditioning flags wait to be read (uniform)
+  bool prev_ill = false;   // (thread 0) the previous tile was ill-conditioned
   uint64_t pend_tile = 0;
+  float* wmax = reinterpret_cast<float*>(misc + 352);  // [waves]: largest window energy of each wave's samples
   int rbase = STATIC ? R - SYNC_TILE : 0;  // the slot of the tile's first sample
   auto RW = [R](int s_) { return STATIC ? s_ : ring_wrap(s_, R); };
   // the next tile of y, fetched a tile ahead: its HBM latency hides behind the metric phase
@@ -648,9 +703,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     int tl = tid;
     asm volatile("" : "+v"(tl));
     const uint64_t t0 = tile * (uint64_t)T;
-    const int64_t t0s = (int64_t)t0;
     const bool owned = tile >= tile_own0;
-    const bool masked = warm && (t0s < qvalid + D);  // some sample of the tile lacks real history
 
     // ---- 1. the tile of y into the ring.  Ring hazards: the slots written hold samples more than HY before this
     //         tile -- every read of them happened before the last barrier of the previous iteration.
@@ -691,8 +744,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     __syncthreads();  // B2: the tile's y is in the ring
     STAMP(2);
     if (pend) {  // the previous tile's summary: every wave wrote its slot before this barrier
-      if (tid == 0) sync_finish_tile(p, slots, pend_tile);
-      pend = false;
+      if (tid == 0) prev_ill = pend_warm ? sync_tile_ill(slots, pend_tile) : sync_finish_tile(p, slots, pend_tile, prev_ill);
+      pend = pend_warm = false;
     }
     const int ybs = RW(rbase + SYNC_V * tl);
     const int yb = sync_lp(ybs), yb1 = sync_lp(RW(ybs - D)), yb2 = sync_lp(RW(RW(ybs - D) - D));
@@ -707,7 +760,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     float pfe[SYNC_V];
     F3 tsum = {0.f, 0.f, 0.f};
     F3 anc = {0.f, 0.f, 0.f};
-    if (!masked) {
+    {
       cv tri = {0.f, 0.f};
       float te = 0.f;
 #pragma unroll
@@ -734,41 +787,6 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
       }
       anc.a = ari.x;
       anc.b = ari.y;
-    } else {
-#pragma unroll
-      for (int j = 0; j < SYNC_V; j++) {
-        const int64_t n = t0s + SYNC_V * tl + j;
-        const c32 a = ys[yb + j];
-        const c32 d1 = ys[yb1 + j];
-        const c32 d2 = ys[yb2 + j];
-        float nr = 0.f, ni = 0.f, ne = 0.f, orr = 0.f, oi = 0.f, oe = 0.f;
-        if (n >= qvalid) {
-          nr = fmaf(a.re, d1.re, a.im * d1.im);
-          ni = fmaf(a.im, d1.re, -(a.re * d1.im));
-          ne = fmaf(a.re, a.re, a.im * a.im);
-        }
-        if (n >= qvalid + D) {
-          orr = fmaf(d1.re, d2.re, d1.im * d2.im);
-          oi = fmaf(d1.im, d2.re, -(d1.re * d2.im));
-          oe = fmaf(d1.re, d1.re, d1.im * d1.im);
-        }
-        tsum.a += nr - orr;
-        tsum.b += ni - oi;
-        tsum.c += ne - oe;
-        pri[j].x = tsum.a;
-        pri[j].y = tsum.b;
-        pfe[j] = tsum.c;
-      }
-      for (int m = -D + tl; m < 0; m += SYNC_THREADS) {
-        if (t0s + m >= qvalid) {
-          const int sa = RW(rbase + m);
-          const c32 a = ys[sync_lp(sa)];
-          const c32 d1 = ys[sync_lp(RW(sa - D))];
-          anc.a += fmaf(a.re, d1.re, a.im * d1.im);
-          anc.b += fmaf(a.im, d1.re, -(a.re * d1.im));
-          anc.c += fmaf(a.re, a.re, a.im * a.im);
-        }
-      }
     }
     STAMP(3);
     F3 ex3, anch;
@@ -785,24 +803,26 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     bri.x = anch.a + ex3.a;
     bri.y = anch.b + ex3.b;
     const float be = anch.c + ex3.c;
+    float rlo = INFINITY, rhi = -INFINITY;  // smallest / largest window energy among this thread's samples
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) {
       const cv pq = bri + pri[j];
       const float r = be + pfe[j];
+      rlo = fminf(rlo, r);
+      rhi = fmaxf(rhi, r);
       const float num = fmaf(pq.x, pq.x, pq.y * pq.y);
-      // pre-selection only: 1-ulp reciprocal (an IEEE divide costs ten instructions).  R = 0 means P = 0 too: the
-      // floor on the denominator gives the 0/0 -> 0 of the normative metric without a compare and select.
-      float m = num * __builtin_amdgcn_rcpf(fmaxf(r * r, 1e-37f));
+      // IEEE division (correctly rounded: part of the normative schedule -- a hardware reciprocal has no bits another
+      // machine can reproduce).  R = 0 means P = 0 too: the floor on the denominator gives the 0/0 -> 0 of the normative
+      // metric without a compare and select.
+      float m = num / fmaxf(r * r, 1e-37f);
       m = fminf(m, 1024.0f);  // (NaN -- Inf/Inf on garbage input -- goes to 1024 as well: fminf returns the number)
       Mv[j] = m;
     }
-    if (masked) {  // (a warm-up tile: samples whose windows reach before the segment's first loaded sample)
-#pragma unroll
-      for (int j = 0; j < SYNC_V; j++)
-        if (t0s + SYNC_V * tl + j < mvalid) Mv[j] = 0.0f;
-    }
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) mt[mb + j] = Mv[j];
+    // running maximum of the window energy over the tile (for the ill-conditioning test below)
+    const float rinc = wave_incl_scanmax_f32(rhi);
+    if (lane_id() == WAVE - 1) wmax[wave_id()] = rinc;
     __syncthreads();  // B4
     STAMP(5);
 
@@ -833,11 +853,32 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     // the CP newest M values become the next tile's history (every thread has done its reads of mh
     // and mt before B5; mt is free from here on)
     for (int i = tl; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = mt[sync_lp(T - HM + i)];
-    if (!owned) continue;  // warm-up tile: only the histories matter
+    // Float32 has lost the window energy where it fell below SYNC_ILL of the largest value the running sums went
+    // through since the tile's anchor: such a tile goes to the fixed-point evaluation whole (sync_finish_tile).
+    float pmx = fmaxf(anch.c, rinc);
+#pragma unroll
+    for (int i = 0; i < SYNC_THREADS / WAVE - 1; i++)
+      if (i < wave_id()) pmx = fmaxf(pmx, wmax[i]);
+    const bool ill_lane = rlo < SYNC_ILL * pmx;
+    if (!owned) {  // warm-up tile: only the histories matter -- and whether it was ill-conditioned
+      const unsigned long long ib = __ballot(ill_lane);
+      if (lane_id() == WAVE - 1)
+        reinterpret_cast<int*>(slots + ((int)(tile & 1u) * (SYNC_THREADS / WAVE) + wave_id()) * 6)[5] = ib != 0ull;
+      pend = pend_warm = true;
+      pend_tile = tile;
+      continue;
+    }
 
     float u[SYNC_V];
 #pragma unroll
     for (int j = 0; j < SYNC_V; j++) u[j] = (mach + mex + pm[j]) * inv_cp - 1.0f;
+    if (p.presel_tap) {
+#pragma unroll
+      for (int j = 0; j < SYNC_V; j++) {
+        const uint64_t n = t0 + (uint64_t)(SYNC_V * tl + j);
+        if (n < p.nsamples) p.presel_tap[n] = u[j];
+      }
+    }
 
     // ---- 6. tile summary of the detector's running average; float32 pre-selection --------------
     int nv = 0;
@@ -866,9 +907,8 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     if (t0 + (uint64_t)T > p.nsamples) {
       // the (short) last tile: weight by the samples that follow this thread's
       const int64_t after = (int64_t)(p.nsamples - t0) - (int64_t)(SYNC_V * tl + nv);
-      wgt = (float)pow(p.decay, (double)(after > 0 ? after : 0));
+      wgt = (float)p.dpow[after > 0 ? after : 0];
     }
-    if (p.exact_all) amask = (1u << nv) - 1u;
     // Each WAVE leaves its part of the tile's summary in an LDS slot and moves on -- no workgroup barrier here; thread 0
     // puts the parts together after the next barrier the loop meets anyway (B2 of the next tile, or the one after the
     // loop).  A wave's part: the weighted sum S of its samples; whether it saw a candidate; and if so the first / last
@@ -877,6 +917,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     // after it Post + S of the later waves -- added in wave order, the same additions as a block-wide scan would do.
     {
       float sw = wave_incl_scan1_f32(floc * wgt);
+      const unsigned long long ib = __ballot(ill_lane && nv > 0);
       const unsigned long long cb = __ballot(amask != 0);
       int amin_w = T, bmax_w = -1;
       float pre_w = 0.f, post_w = 0.f;
@@ -907,15 +948,16 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
         sl[2] = post_w;
         reinterpret_cast<int*>(sl)[3] = amin_w;
         reinterpret_cast<int*>(sl)[4] = bmax_w;
+        reinterpret_cast<int*>(sl)[5] = ib != 0ull;
       }
     }
     pend = true;
     pend_tile = tile;
     STAMP(7);
   }
-  if (pend) {
+  if (pend && !pend_warm) {
     __syncthreads();
-    if (tid == 0) sync_finish_tile(p, slots, pend_tile);
+    if (tid == 0) sync_finish_tile(p, slots, pend_tile, prev_ill);
   }
 #ifdef SYNC_STAMPS
   if (p.stamps && threadIdx.x == 0)
@@ -956,32 +998,40 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
   float* ue = reinterpret_cast<float*>(smem + L.ue);
   unsigned char* misc = smem + L.misc;
   long long* sc_i64 = reinterpret_cast<long long*>(misc);      // 24 entries
-  double* sc_f64 = reinterpret_cast<double*>(misc + 192);      // 2 * 5 entries
-  int* sc_i32 = reinterpret_cast<int*>(misc + 272);            // 5 entries
   unsigned long long* bc = reinterpret_cast<unsigned long long*>(misc + 320);  // 2 broadcast words (chunk allocation)
   const int D = p.D, CP = p.CP;
-  const unsigned long long nrec = *p.rec_count;
+  // the metric tap's pass walks every tile over its whole length and writes nothing but the tap
+  const unsigned long long nrec = p.tap_only ? (unsigned long long)p.ntiles : *p.rec_count;
   // current allocation chunks of this workgroup (uniform across the block)
   unsigned long long cand_base = 0, piece_base = 0;
   uint32_t cand_left = 0, piece_left = 0;
+  const double alpha_d = (double)p.alpha;
 
   for (unsigned long long ri = blockIdx.x; ri < nrec; ri += gridDim.x) {
-    const SyncRec rec = p.recs[ri];
+    SyncRec rec;
+    if (p.tap_only) {
+      rec.tile = ri;
+      rec.amin = 0;
+      const uint64_t left = p.nsamples - ri * (uint64_t)T;
+      rec.bmax = (left < (uint64_t)T ? (int)left : T) - 1;
+      rec.gpre = rec.gpost = 0.f;
+    } else {
+      rec = p.recs[ri];
+    }
     const uint64_t tile = rec.tile;
     const int amin = rec.amin, bmax = rec.bmax;
-    if ((bmax - amin + 1 <= p.exact_small) != SMALL) continue;  // the other launch's record
+    if (!p.tap_only && (bmax - amin + 1 <= p.exact_small) != SMALL) continue;  // the other launch's record
     const uint64_t t0 = tile * (uint64_t)T;
     const int64_t t0s = (int64_t)t0;
-    // the segment this tile was walked in: samples before its warm-up start count as unknown (k_sync's masks)
-    const uint64_t seg = tile / (uint64_t)p.tiles_per_seg;
-    const bool warm = seg > 0;
-    const uint64_t ws = warm ? (seg * (uint64_t)p.tiles_per_seg - (uint64_t)p.nwarm) * (uint64_t)T : 0;
-    const int64_t qvalid = warm ? (int64_t)(ws + (uint64_t)D) : 0;
-    const int64_t mvalid = warm ? (int64_t)(ws + 2ull * (uint64_t)D) - 1 : 0;
     const int Tl = (t0 + (uint64_t)T <= p.nsamples) ? T : (int)(p.nsamples - t0);  // samples of this tile
+    const int rlen = bmax - amin + 1;
+
+    if (p.tap_only) {
+      sync_exact_range<NT, KEEP>(p.y, me, ue, nullptr, p.metric_tap + t0 + (uint64_t)amin, sc_i64, amin, bmax, D, CP, t0s, p.tapcp);
+      continue;  // (sync_exact_range ends with a barrier: me / ue / scratch are free again)
+    }
 
     // ---- 7. fixed-point re-evaluation of [amin, bmax]; stored as this tile's candidate values (u, P) ----
-    const int rlen = bmax - amin + 1;
     if ((uint32_t)rlen > cand_left) {
       if (tl == 0) bc[0] = atomicAdd(p.cand_count, (unsigned long long)CHUNK_C);  // fresh chunk
       __syncthreads();
@@ -994,68 +1044,28 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
     cand_base += (unsigned long long)rlen;
     cand_left -= (uint32_t)rlen;
     if (fits) {
-      sync_exact_range<NT, KEEP>(p.y, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, t0s, qvalid, mvalid, p.tapcp);
+      sync_exact_range<NT, KEEP>(p.y, me, ue, p.cand_P + cbase, p.cand_u + cbase, sc_i64, amin, bmax, D, CP, t0s, p.tapcp);
     } else {
       for (int i = tl; i < rlen; i += NT) ue[i] = -1.0f;  // nothing can be stored: no candidates
       __syncthreads();
     }
 
-    // ---- 8. pieces and summary: each thread walks lc consecutive samples of the range ----
+    // ---- 8. pieces and summary: each thread walks lc consecutive samples of the range.  The range's part of the
+    //      detector average is a sum of Q40-rounded float64 products alpha * u[k] * decay^(Tl-1-k) (weights to the
+    //      tile's end): integer addition has no order, so this scan, the oracle's running sum and any other split
+    //      of the range give the same bits.
     const int lc = (rlen + NT - 1) / NT;
     const int j0 = tl * lc, j1 = (j0 + lc < rlen) ? (j0 + lc) : rlen;
-    Aff f;
-    f.A = 1.0;
-    f.b = 0.0;
+    long long xq = 0;
     int nstart = 0;
     for (int k = j0; k < j1; k++) {
       const float ux = ue[k];
-      f.A = f.A * p.decay;
-      f.b = (double)p.alpha * (double)ux + p.decay * f.b;
+      xq += q40_from_double((alpha_d * (double)ux) * p.dpow[Tl - 1 - (amin + k)]);
       if (ux > p.cand_thr && !(k > 0 && ue[k - 1] > p.cand_thr)) nstart++;
-      if (p.metric_tap) p.metric_tap[t0 + (uint64_t)(amin + k)] = ux;
     }
-    Aff inc = f;
-    {
-      const int lane = lane_id(), w = wave_id();
-#pragma unroll
-      for (int d = 1; d < WAVE; d <<= 1) {
-        Aff o;
-        o.A = __shfl_up(inc.A, d, WAVE);
-        o.b = __shfl_up(inc.b, d, WAVE);
-        if (lane >= d) inc = aff_then(o, inc);
-      }
-      if (lane == WAVE - 1) {
-        sc_f64[2 * w] = inc.A;
-        sc_f64[2 * w + 1] = inc.b;
-      }
-    }
-    __syncthreads();
-    Aff pre, tot;
-    pre.A = tot.A = 1.0;
-    pre.b = tot.b = 0.0;
-    {
-      const int w = wave_id();
-      for (int i = 0; i < NT / WAVE; i++) {
-        Aff g;
-        g.A = sc_f64[2 * i];
-        g.b = sc_f64[2 * i + 1];
-        if (i < w) pre = aff_then(pre, g);
-        tot = aff_then(tot, g);
-      }
-      Aff prev;
-      prev.A = __shfl_up(inc.A, 1, WAVE);
-      prev.b = __shfl_up(inc.b, 1, WAVE);
-      if (lane_id() == 0) {
-        prev.A = 1.0;
-        prev.b = 0.0;
-      }
-      pre = aff_then(pre, prev);
-    }
-    // the detector average (zero at the tile start) just before amin, from k_sync's float32 sum weighted to the tile's end
-    const double a0 = (double)rec.gpre * pow(p.decay, -(double)(Tl - amin));
-    int ptot;
-    const int nstart_before = block_excl_scan_add<int>(nstart, sc_i32, &ptot);
-    const int npieces = ptot;
+    Q3 v3 = {xq, (long long)nstart, 0}, ex, tot;
+    block_scan3_sum3_i64<NT>(v3, v3, sc_i64, &ex, &tot);
+    const int npieces = (int)tot.pi;
     if ((uint32_t)npieces > piece_left) {
       if (tl == 0) bc[1] = atomicAdd(p.piece_count, (unsigned long long)SYNC_CHUNK_P);  // fresh chunk
       __syncthreads();
@@ -1066,8 +1076,8 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
     fits = fits && (basep + (unsigned long long)npieces <= p.piece_cap);
     if (!fits && tl == 0) atomicOr(p.overflow, 1u);
     if (fits && npieces > 0) {
-      double a_loc = pre.A * a0 + pre.b;  // average just before this thread's first sample
-      int so = nstart_before;
+      long long X = ex.pr;  // the range's samples before this thread's first
+      int so = (int)ex.pi;
       for (int k = j0; k < j1; k++) {
         const float ux = ue[k];
         const bool cand = ux > p.cand_thr;
@@ -1076,16 +1086,17 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
           SyncPiece* pc = p.pieces + basep + so;
           pc->start = n;
           pc->val_off = cbase + (unsigned long long)k;
-          pc->bloc = a_loc;
+          // the average (zero at the tile start) just before this sample: everything before it, weighted to the tile's
+          // end, carried back by 1 / decay^(Tl - s)
+          pc->bloc = ((double)rec.gpre + (double)X * Q40_INV) * p.ipow[Tl - (amin + k)];
           so++;
         }
         if (cand && !(k + 1 < rlen && ue[k + 1] > p.cand_thr)) p.pieces[basep + so - 1].end = n;
-        a_loc = (double)p.alpha * (double)ux + p.decay * a_loc;
+        X += q40_from_double((alpha_d * (double)ux) * p.dpow[Tl - 1 - (amin + k)]);
       }
     }
     if (tl == 0) {
-      // average after bmax, carried to the tile's end, plus what follows the range
-      p.tile_B[tile] = (tot.A * a0 + tot.b) * pow(p.decay, (double)(Tl - 1 - bmax)) + (double)rec.gpost;
+      p.tile_B[tile] = ((double)rec.gpre + (double)tot.pr * Q40_INV) + (double)rec.gpost;
       p.tile_npieces[tile] = fits ? (uint32_t)npieces : 0u;
       p.tile_first[tile] = basep;
     }
@@ -1101,11 +1112,12 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
 // avg carry-in per tile: avg_in[g] = running average just before the tile's first sample
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_avg_carry(const double* __restrict__ tile_B, uint64_t ntiles, uint64_t nsamples,
-                                                    double decay, double* __restrict__ avg_in) {
+                                                    const double* __restrict__ dpow, double* __restrict__ avg_in) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ntiles) return;
-  // every earlier tile is full (only the last tile of the stream can be short)
-  const double A = pow(decay, (double)SYNC_TILE);
+  // every earlier tile is full (only the last tile of the stream can be short); normative: k ascending, product and sum
+  // separately rounded, cut-off where the weight has dropped below 1e-30
+  const double A = dpow[SYNC_TILE];
   double acc = 0.0, w = 1.0;
   for (uint64_t k = 1; k <= g; k++) {
     acc += w * tile_B[g - k];
@@ -1123,7 +1135,7 @@ __global__ void __launch_bounds__(256) k_avg_carry(const double* __restrict__ ti
 struct PeakParams {
   uint64_t ntiles, nsamples;
   float rise, fall, alpha;
-  double decay;
+  const double* dpow;  // decay^j, j = 0..SYNC_TILE (SyncParams)
   const uint32_t* tile_npieces;
   const uint64_t* tile_first;
   const SyncPiece* pieces;
@@ -1158,7 +1170,7 @@ __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
       const uint32_t npp = p.tile_npieces[g - 1];
       if (npp > 0 && p.pieces[p.tile_first[g - 1] + npp - 1].end + 1 == pc.start) continue;
     }
-    float avg = (float)(p.avg_in[g] * pow(p.decay, (double)(pc.start - g * (uint64_t)SYNC_TILE)) + pc.bloc);
+    float avg = (float)(p.avg_in[g] * p.dpow[pc.start - g * (uint64_t)SYNC_TILE] + pc.bloc);
     int state = 0;
     float peak_val = -INFINITY;
     uint64_t peak_ind = 0;

@@ -367,7 +367,7 @@ class Engine(object):
         _abi.TAP_RX_FRAMES: np.uint64, _abi.TAP_RX_FFT: np.complex64, _abi.TAP_RX_ACQ: np.complex64,
         _abi.TAP_RX_SINK: np.complex64, _abi.TAP_RX_PACKETS: np.uint8, _abi.TAP_TX_MAPPER: np.complex64,
         _abi.TAP_TX_IFFT: np.complex64, _abi.TAP_RX_SAMPLER: np.complex64, _abi.TAP_RX_SIGMIX: np.complex64,
-        _abi.TAP_RX_NCO: np.complex64,
+        _abi.TAP_RX_NCO: np.complex64, _abi.TAP_RX_PRESEL: np.float32,
     }
 
     def tap(self, tap):

@@ -763,6 +763,10 @@ struct orc_rx_result {
   vec y;        /* c32 */
   vec metric;   /* f32 */
   vec peaks;    /* u64 */
+  vec peaks_gr; /* u64: flags of the literal float32 recurrence (cross-check, ORC_TAP_PEAKS_GR) */
+  vec presel;   /* f32 [nsamples]: float32 pre-selection metric (OFDM_TAP_RX_PRESEL) */
+  vec ranges;   /* i32 [ntiles][2]: exact-evaluation range of every 2048-sample tile, -1 -1 = none (ORC_TAP_RANGES) */
+  uint64_t presel_miss; /* samples with exact u > theta outside every range (must be 0: see orc_rx_presel_miss) */
   vec angles;   /* f32 */
   vec frames;   /* u64 x2 */
   vec fft;      /* c32 */
@@ -896,8 +900,11 @@ static void sync_metric(const ofdm_cfg *cfg, const ofdm_c32 *y, uint64_t n, floa
   free(qm);
 }
 
-/* gr_peak_detector_fb(0.20, 0.20, 30, 0.001) over the whole stream as one buffer */
-static void peak_detect(const ofdm_cfg *cfg, const float *u, uint64_t n, vec *peaks) {
+/* gr_peak_detector_fb(0.20, 0.20, 30, 0.001) over the whole stream as one buffer, LITERALLY: the running average
+ * as the float32 recurrence avg = alpha*u + (1-alpha)*avg from the first sample on.  Kept as the cross-check of the
+ * normative evaluation below (ORC_TAP_PEAKS_GR): the two give the same flags unless a comparison u > avg*factor
+ * falls inside the recurrence's own float32 rounding noise (~1e-6). */
+static void peak_detect_gr(const ofdm_cfg *cfg, const float *u, uint64_t n, vec *peaks) {
   float rise = cfg->peak_rise, fall = cfg->peak_fall, alpha = cfg->peak_alpha;
   float one_m_alpha = 1.0f - alpha;
   float avg = 0.0f, peak_val = -INFINITY;
@@ -929,6 +936,406 @@ static void peak_detect(const ofdm_cfg *cfg, const float *u, uint64_t n, vec *pe
     }
   }
   /* a run still open at the end of the stream raises no flag (GR would wait for more input) */
+}
+
+/* ------------------------------------------------------------------------ */
+/* gr_peak_detector_fb, NORMATIVE evaluation (what the engine runs).
+ *
+ * The detector's average obeys avg = alpha*u + (1-alpha)*avg on every sample whatever its state, and the state
+ * machine can only act where u > theta = -max(rise, fall) (avg >= -1, so both thresholds are >= theta): maximal
+ * runs {u > theta} are independent once avg at their first sample is known.  A float32 recurrence from the first
+ * sample of the stream has no value a parallel machine can reproduce, so -- as for the moving sums and the
+ * transforms -- ONE evaluation of that starting value is fixed here and the engine performs the same one:
+ *
+ *  1. Tiles of 2048 samples on the grid of the call's first sample.  A cheap float32 evaluation of the metric
+ *     (u32, "pre-selection") of every tile in a fixed schedule: 256 lanes of 8 consecutive samples, the window
+ *     sums P, R anchored afresh at the tile start (lane-strided partial sums over the D samples before it), lane
+ *     chains + the 64-lane scan network below + the four groups in order; M = |P|^2 / max(R^2, 1e-37) (IEEE
+ *     division), min(M, 1024); the CP-length mean of M the same way from the CP values before the tile.
+ *  2. The samples with u32 > theta - 1e-3 of a tile span its RANGE [amin, bmax]; there u is evaluated in the
+ *     normative Q23.40 arithmetic (sync_metric above), and only there can a candidate lie.
+ *  3. The tile's contribution to the average, B = sum_k alpha * decay^(Tl-1-k) * u[k]: outside the range from
+ *     u32, in float32 (a lane's chain fmaf(., 1-alpha, alpha*u) over its 8 samples, times decay^(samples after the
+ *     lane), scan network, groups in order); inside it from the exact u as a sum of Q40-rounded float64 products
+ *     (integer sum: no order).  The average before a tile: sum_{k>=1} decay^(2048 k) * B[g-k], k ascending, until
+ *     the weight drops below 1e-30.
+ *  4. At the first sample s of a run: avg = float32(avg_before_tile * decay^s + (Bpre + X(s)) / decay^(Tl - s)),
+ *     X(s) the exact part up to s-1; from there the float32 recurrence and gr_peak_detector_fb's state machine,
+ *     through following tiles while the run goes on.
+ * decay^j is the table d[0] = 1, d[j] = d[j-1] * (double)(1.0f - alpha).                                        */
+/* ------------------------------------------------------------------------ */
+#define SY_T 2048
+#define SY_NTH 256
+#define SY_V 8
+#define SY_GUARD 1.0e-3f
+#define SY_ILL 0.015625f /* 1/64 */
+
+typedef struct {
+  uint64_t start, end; /* absolute sample indices */
+  double bloc;         /* zero-initialised average over the tile's samples before start */
+} sy_piece;
+
+/* the 64-lane inclusive scan network (four shifts inside rows of 16 lanes, then two row broadcasts); every step
+ * reads all its inputs before writing */
+static void sy_scan64(float *v) {
+  float o[64];
+  static const int sh[4] = {1, 2, 4, 8};
+  for (int s = 0; s < 4; s++) {
+    memcpy(o, v, sizeof(o));
+    for (int i = 0; i < 64; i++)
+      if ((i & 15) >= sh[s]) v[i] = o[i - sh[s]] + o[i];
+  }
+  memcpy(o, v, sizeof(o));
+  for (int i = 16; i < 32; i++) v[i] = o[15] + o[i];
+  for (int i = 48; i < 64; i++) v[i] = o[47] + o[i];
+  memcpy(o, v, sizeof(o));
+  for (int i = 32; i < 64; i++) v[i] = o[31] + o[i];
+}
+/* exclusive scan of v over the 256 lanes and the total of s: the network per group of 64, the groups' totals in order */
+static void sy_block_scan(const float *v, const float *s, float *excl, float *sum) {
+  float inc[SY_NTH], rs[SY_NTH];
+  memcpy(inc, v, sizeof(inc));
+  memcpy(rs, s, sizeof(rs));
+  for (int w = 0; w < SY_NTH / 64; w++) {
+    sy_scan64(inc + 64 * w);
+    sy_scan64(rs + 64 * w);
+  }
+  float sm = 0.0f;
+  for (int w = 0; w < SY_NTH / 64; w++) sm += rs[64 * w + 63];
+  for (int w = 0; w < SY_NTH / 64; w++) {
+    float base = 0.0f;
+    for (int i = 0; i < w; i++) base += inc[64 * i + 63];
+    for (int l = 0; l < 64; l++) {
+      int t = 64 * w + l;
+      excl[t] = base + inc[t] - v[t];
+    }
+  }
+  *sum = sm;
+}
+/* a * conj(w) with the placement of fused operations the engine's packed instructions have */
+static inline ofdm_c32 sy_cmulc(ofdm_c32 a, ofdm_c32 w) {
+  return c32(fmaf(a.re, w.re, a.im * w.im), fmaf(a.re, -w.im, a.im * w.re));
+}
+static inline int64_t sy_q40d(double x) { return (int64_t)llrint(x * QSCALE); }
+
+typedef struct {
+  int amin, bmax;     /* range, tile-relative; bmax < 0: none */
+  float gpre, gpost;  /* float32 part of B before / after the range (no range: gpre = the whole tile) */
+} sy_tile;
+
+static void peak_detect(const ofdm_cfg *cfg, const ofdm_c32 *y, const float *ux, uint64_t n, vec *peaks, float *u32_tap,
+                        int32_t *range_tap, uint64_t *presel_miss) {
+  const int T = SY_T, D = (int)cfg->fft_length / 2, CP = (int)cfg->cp_length;
+  const float rise = cfg->peak_rise, fall = cfg->peak_fall, alpha = cfg->peak_alpha;
+  const float one_m_alpha = 1.0f - alpha, decay_f = one_m_alpha;
+  const double decay = (double)one_m_alpha, alpha_d = (double)alpha;
+  const float theta = -fmaxf(rise, fall), athr = theta - SY_GUARD;
+  const float inv_cp = 1.0f / (float)CP;
+  const uint64_t ntiles = (n + (uint64_t)T - 1) / (uint64_t)T;
+  double *dpow = (double *)malloc(sizeof(double) * (size_t)(T + 1));
+  dpow[0] = 1.0;
+  for (int j = 1; j <= T; j++) dpow[j] = dpow[j - 1] * decay;
+  float wf[SY_NTH];
+  for (int t = 0; t < SY_NTH; t++) wf[t] = (float)dpow[T - SY_V * (t + 1)];
+  sy_tile *tl = (sy_tile *)calloc(ntiles ? ntiles : 1, sizeof(sy_tile));
+  double *B = (double *)calloc(ntiles ? ntiles : 1, sizeof(double));
+  float *mh = (float *)calloc((size_t)CP, sizeof(float)); /* M of the CP samples before the tile */
+  float *mt = (float *)malloc(sizeof(float) * (size_t)T);
+  float *useq = (float *)malloc(sizeof(float) * (size_t)T);
+#define SY_Y(ix) (((ix) >= 0 && (uint64_t)(ix) < n) ? y[(ix)] : c32(0.0f, 0.0f))
+  /* ---- 1-3: pre-selection metric, range and float32 summary of every tile ---- */
+  int prev_ill = 0;
+  for (uint64_t g = 0; g < ntiles; g++) {
+    const int64_t t0 = (int64_t)(g * (uint64_t)T);
+    const int Tl = (t0 + T <= (int64_t)n) ? T : (int)((int64_t)n - t0);
+    float pr[SY_NTH][SY_V], pi[SY_NTH][SY_V], pe[SY_NTH][SY_V];
+    float va[SY_NTH], vb[SY_NTH], vc[SY_NTH], sa[SY_NTH], sb[SY_NTH], sc[SY_NTH];
+    for (int t = 0; t < SY_NTH; t++) {
+      float tr = 0.0f, ti = 0.0f, te = 0.0f;
+      for (int j = 0; j < SY_V; j++) {
+        const int64_t i = t0 + SY_V * t + j;
+        const ofdm_c32 a = SY_Y(i), d1 = SY_Y(i - D), d2 = SY_Y(i - 2 * D);
+        const ofdm_c32 pa = sy_cmulc(a, d1), pb = sy_cmulc(d1, d2);
+        tr = tr + (pa.re - pb.re);
+        ti = ti + (pa.im - pb.im);
+        te += fmaf(a.re, a.re, a.im * a.im) - fmaf(d1.re, d1.re, d1.im * d1.im);
+        pr[t][j] = tr;
+        pi[t][j] = ti;
+        pe[t][j] = te;
+      }
+      va[t] = tr;
+      vb[t] = ti;
+      vc[t] = te;
+      /* anchor: the window sums at the sample before the tile, lane t takes the terms t, t+256, ... of the window */
+      float ar = 0.0f, ai = 0.0f, ae = 0.0f;
+      for (int m = -D + t; m < 0; m += SY_NTH) {
+        const ofdm_c32 a = SY_Y(t0 + m), d1 = SY_Y(t0 + m - D);
+        const ofdm_c32 pa = sy_cmulc(a, d1);
+        ar = ar + pa.re;
+        ai = ai + pa.im;
+        ae += fmaf(a.re, a.re, a.im * a.im);
+      }
+      sa[t] = ar;
+      sb[t] = ai;
+      sc[t] = ae;
+    }
+    float ea[SY_NTH], eb[SY_NTH], ec[SY_NTH], anca, ancb, ancc;
+    sy_block_scan(va, sa, ea, &anca);
+    sy_block_scan(vb, sb, eb, &ancb);
+    sy_block_scan(vc, sc, ec, &ancc);
+    float rmn[SY_NTH], rmx[SY_NTH];
+    for (int t = 0; t < SY_NTH; t++) {
+      const float bx = anca + ea[t], by = ancb + eb[t], be = ancc + ec[t];
+      float lo = INFINITY, hi = -INFINITY;
+      for (int j = 0; j < SY_V; j++) {
+        const float px = bx + pr[t][j], py = by + pi[t][j], r = be + pe[t][j];
+        const float num = fmaf(px, px, py * py);
+        float m = num / fmaxf(r * r, 1e-37f);
+        m = fminf(m, 1024.0f);
+        mt[SY_V * t + j] = m;
+        lo = fminf(lo, r);
+        hi = fmaxf(hi, r);
+      }
+      rmn[t] = lo;
+      rmx[t] = hi;
+    }
+    /* CP-length mean of M: position i of [history | tile] holds M[n - CP] of the tile's sample i */
+    float pm[SY_NTH][SY_V], vm[SY_NTH], sm_[SY_NTH], em[SY_NTH], mach;
+    for (int t = 0; t < SY_NTH; t++) {
+      float ms = 0.0f;
+      for (int j = 0; j < SY_V; j++) {
+        const int i = SY_V * t + j;
+        ms += mt[i] - ((i < CP) ? mh[i] : mt[i - CP]);
+        pm[t][j] = ms;
+      }
+      vm[t] = ms;
+      float ma = 0.0f;
+      for (int m = -CP + t; m < 0; m += SY_NTH) ma += mh[CP + m];
+      sm_[t] = ma;
+    }
+    sy_block_scan(vm, sm_, em, &mach);
+    for (int t = 0; t < SY_NTH; t++)
+      for (int j = 0; j < SY_V; j++) useq[SY_V * t + j] = (mach + em[t] + pm[t][j]) * inv_cp - 1.0f;
+    for (int i = 0; i < CP; i++) mh[i] = mt[T - CP + i];
+    if (u32_tap)
+      for (int i = 0; i < Tl; i++) u32_tap[t0 + i] = useq[i];
+    /* range and float32 summary */
+    float fl[SY_NTH], wg[SY_NTH];
+    unsigned am[SY_NTH];
+    int nvv[SY_NTH];
+    for (int t = 0; t < SY_NTH; t++) {
+      float f = 0.0f;
+      unsigned a = 0;
+      int nv = 0;
+      for (int j = 0; j < SY_V; j++) {
+        const int i = SY_V * t + j;
+        if (i < Tl) {
+          nv++;
+          f = fmaf(f, decay_f, alpha * useq[i]);
+          if (useq[i] > athr) a |= 1u << j;
+        }
+      }
+      fl[t] = f;
+      am[t] = a;
+      nvv[t] = nv;
+      if (Tl == T) {
+        wg[t] = wf[t];
+      } else {
+        int after = Tl - (SY_V * t + nv);
+        wg[t] = (float)dpow[after > 0 ? after : 0];
+      }
+    }
+    /* Where the window energy R has fallen below 1/64 of the largest value the running sums went through since the tile's
+     * anchor, float32 has lost it to cancellation: such a tile -- and the one after it, whose first CP means still
+     * average this tile's M -- is evaluated in fixed point over its whole length.  (A maximum has no rounding: the
+     * running maximum is the same in any order.) */
+    int ill = 0;
+    {
+      float pm = ancc;
+      for (int t = 0; t < SY_NTH; t++) {
+        pm = fmaxf(pm, rmx[t]);
+        if (nvv[t] > 0 && rmn[t] < SY_ILL * pm) ill = 1;
+      }
+    }
+    const int escalate = ill || prev_ill;
+    prev_ill = ill;
+    float S[4], Pre[4] = {0, 0, 0, 0}, Post[4] = {0, 0, 0, 0};
+    int amin_w[4], bmax_w[4];
+    for (int w = 0; w < 4; w++) {
+      float sv[64];
+      for (int l = 0; l < 64; l++) sv[l] = fl[64 * w + l] * wg[64 * w + l];
+      sy_scan64(sv);
+      S[w] = sv[63];
+      amin_w[w] = T;
+      bmax_w[w] = -1;
+      int l0 = -1, l1 = -1;
+      for (int l = 0; l < 64; l++)
+        if (am[64 * w + l]) {
+          if (l0 < 0) l0 = l;
+          l1 = l;
+        }
+      if (l0 >= 0) {
+        const unsigned m0 = am[64 * w + l0], m1 = am[64 * w + l1];
+        amin_w[w] = SY_V * (64 * w + l0) + __builtin_ctz(m0);
+        bmax_w[w] = SY_V * (64 * w + l1) + 31 - __builtin_clz(m1);
+        float pv[64], qv[64];
+        for (int l = 0; l < 64; l++) {
+          const int t = 64 * w + l;
+          float fpre = 0.0f, fpost = 0.0f;
+          for (int j = 0; j < SY_V; j++)
+            if (j < nvv[t]) {
+              const int i = SY_V * t + j;
+              fpre = fmaf(fpre, decay_f, alpha * ((i < amin_w[w]) ? useq[i] : 0.0f));
+              fpost = fmaf(fpost, decay_f, alpha * ((i > bmax_w[w]) ? useq[i] : 0.0f));
+            }
+          pv[l] = fpre * wg[t];
+          qv[l] = fpost * wg[t];
+        }
+        sy_scan64(pv);
+        sy_scan64(qv);
+        Pre[w] = pv[63];
+        Post[w] = qv[63];
+      }
+    }
+    int w0 = -1, w1 = -1;
+    for (int w = 0; w < 4; w++)
+      if (bmax_w[w] >= 0) {
+        if (w0 < 0) w0 = w;
+        w1 = w;
+      }
+    if (escalate) {
+      tl[g].amin = 0;
+      tl[g].bmax = Tl - 1;
+      tl[g].gpre = tl[g].gpost = 0.0f;
+      int64_t X = 0;
+      for (int k = 0; k < Tl; k++) X += sy_q40d((alpha_d * (double)ux[t0 + k]) * dpow[Tl - 1 - k]);
+      B[g] = (0.0 + (double)X * QINV) + 0.0;
+    } else if (w0 < 0) {
+      tl[g].amin = T;
+      tl[g].bmax = -1;
+      tl[g].gpre = (S[0] + S[1]) + (S[2] + S[3]);
+      tl[g].gpost = 0.0f;
+      B[g] = (double)tl[g].gpre;
+    } else {
+      float ga = 0.0f, gb = 0.0f;
+      for (int w = 0; w < 4; w++) {
+        ga += (w < w0) ? S[w] : (w == w0) ? Pre[w] : 0.0f;
+        gb += (w > w1) ? S[w] : (w == w1) ? Post[w] : 0.0f;
+      }
+      tl[g].amin = amin_w[w0];
+      tl[g].bmax = bmax_w[w1];
+      tl[g].gpre = ga;
+      tl[g].gpost = gb;
+      /* the exact part: Q40-rounded products alpha*u*decay^(Tl-1-k), summed as integers */
+      int64_t X = 0;
+      for (int k = tl[g].amin; k <= tl[g].bmax; k++) X += sy_q40d((alpha_d * (double)ux[t0 + k]) * dpow[Tl - 1 - k]);
+      B[g] = ((double)ga + (double)X * QINV) + (double)gb;
+    }
+    if (range_tap) {
+      range_tap[2 * g] = tl[g].bmax >= 0 ? tl[g].amin : -1;
+      range_tap[2 * g + 1] = tl[g].bmax;
+    }
+    if (presel_miss)
+      for (int i = 0; i < Tl; i++)
+        if (ux[t0 + i] > theta && !(tl[g].bmax >= 0 && i >= tl[g].amin && i <= tl[g].bmax)) (*presel_miss)++;
+  }
+#undef SY_Y
+  /* ---- the average before every tile ---- */
+  double *avg_in = (double *)calloc(ntiles ? ntiles : 1, sizeof(double));
+  {
+    const double A = dpow[T];
+    for (uint64_t g = 0; g < ntiles; g++) {
+      double acc = 0.0, w = 1.0;
+      for (uint64_t k = 1; k <= g; k++) {
+        acc += w * B[g - k];
+        w *= A;
+        if (w < 1e-30) break;
+      }
+      avg_in[g] = acc;
+    }
+  }
+  /* ---- 4: the state machine on every run of candidates ---- */
+  uint64_t g = 0;
+  while (g < ntiles) {
+    if (tl[g].bmax < 0) {
+      g++;
+      continue;
+    }
+    /* runs that START in tile g, in order; a run that reaches the tile's last sample goes on in the next tile */
+    const uint64_t t0 = g * (uint64_t)T;
+    const int Tl = (t0 + (uint64_t)T <= n) ? T : (int)(n - t0);
+    int64_t X = 0;
+    int k = tl[g].amin;
+    while (k <= tl[g].bmax) {
+      const float uk = ux[t0 + (uint64_t)k];
+      if (!(uk > theta)) {
+        X += sy_q40d((alpha_d * (double)uk) * dpow[Tl - 1 - k]);
+        k++;
+        continue;
+      }
+      /* a run starts at k -- unless it continues the previous tile's last run (handled there) */
+      int cont = 0;
+      if (k == 0 && g > 0 && tl[g - 1].bmax == T - 1 && ux[t0 - 1] > theta) cont = 1;
+      if (cont) { /* skip it: walked from the tile it started in */
+        while (k <= tl[g].bmax && ux[t0 + (uint64_t)k] > theta) {
+          X += sy_q40d((alpha_d * (double)ux[t0 + (uint64_t)k]) * dpow[Tl - 1 - k]);
+          k++;
+        }
+        continue;
+      }
+      const double bloc = ((double)tl[g].gpre + (double)X * QINV) * (1.0 / dpow[Tl - k]);
+      float avg = (float)(avg_in[g] * dpow[k] + bloc);
+      int state = 0;
+      float peak_val = -INFINITY;
+      uint64_t peak_ind = 0;
+      uint64_t gg = g;
+      int kk = k;
+      int open_at_end = 0;
+      for (;;) {
+        const uint64_t tt0 = gg * (uint64_t)T;
+        while (kk <= tl[gg].bmax && ux[tt0 + (uint64_t)kk] > theta) {
+          const float u = ux[tt0 + (uint64_t)kk];
+          int s1 = state != 0 || (u > avg * rise);
+          int newpk = s1 && (u > peak_val);
+          if (s1 && !newpk && !(u > avg * fall)) {
+            *(uint64_t *)vec_push(peaks, 1) = peak_ind;
+            peak_val = -INFINITY;
+            s1 = u > avg * rise;
+            newpk = s1 && (u > peak_val);
+          }
+          if (newpk) {
+            peak_val = u;
+            peak_ind = tt0 + (uint64_t)kk;
+          }
+          avg = alpha * u + one_m_alpha * avg;
+          state = s1;
+          kk++;
+        }
+        /* the run reached the end of the range; does it go on in the next tile? */
+        if (kk == T && gg + 1 < ntiles && tl[gg + 1].bmax >= 0 && tl[gg + 1].amin == 0 && ux[tt0 + (uint64_t)T] > theta) {
+          gg++;
+          kk = 0;
+          continue;
+        }
+        if (tt0 + (uint64_t)kk >= n) open_at_end = 1;
+        break;
+      }
+      if (state == 1 && !open_at_end) *(uint64_t *)vec_push(peaks, 1) = peak_ind;
+      /* account for the run's samples inside THIS tile in X, then go on behind it */
+      while (k <= tl[g].bmax && ux[t0 + (uint64_t)k] > theta) {
+        X += sy_q40d((alpha_d * (double)ux[t0 + (uint64_t)k]) * dpow[Tl - 1 - k]);
+        k++;
+      }
+    }
+    g++;
+  }
+  free(avg_in);
+  free(useq);
+  free(mt);
+  free(mh);
+  free(B);
+  free(tl);
+  free(dpow);
 }
 
 typedef struct {
@@ -1061,6 +1468,9 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
   vec_init(&r->y, sizeof(ofdm_c32));
   vec_init(&r->metric, sizeof(float));
   vec_init(&r->peaks, sizeof(uint64_t));
+  vec_init(&r->peaks_gr, sizeof(uint64_t));
+  vec_init(&r->presel, sizeof(float));
+  vec_init(&r->ranges, sizeof(int32_t));
   vec_init(&r->angles, sizeof(float));
   vec_init(&r->frames, sizeof(uint64_t));
   vec_init(&r->fft, sizeof(ofdm_c32));
@@ -1091,7 +1501,10 @@ orc_rx_result *orc_rx(const ofdm_cfg *cfg, const ofdm_c32 *iq, uint64_t n, uint3
     /* --- ofdm_sync_pn ---------------------------------------------------- */
     float *u = (float *)vec_push(&r->metric, n);
     sync_metric(cfg, y, n, u, P);
-    peak_detect(cfg, u, n, &r->peaks);
+    float *u32_tap = (tap_mask & (1u << OFDM_TAP_RX_PRESEL)) ? (float *)vec_push(&r->presel, n) : NULL;
+    int32_t *range_tap = (int32_t *)vec_push(&r->ranges, 2 * (size_t)((n + SY_T - 1) / SY_T));
+    peak_detect(cfg, y, u, n, &r->peaks, u32_tap, range_tap, &r->presel_miss);
+    peak_detect_gr(cfg, u, n, &r->peaks_gr);
   } else {
     /* SYNC = "fixed" (ofdm_receiver.py~:108-119, "for testing only"): chan_filt = gr.multiply_const_cc(1.0);
      * ofdm_sync_fixed: a vector source repeating nsymbols*(N+CP) bytes with a 1 at index (N+CP)-1, and a constant
@@ -1422,6 +1835,9 @@ uint64_t orc_rx_tap(const orc_rx_result *r, int tap, void *out, uint64_t cap_byt
     case OFDM_TAP_RX_CHAN_FILT: v = &r->y; break;
     case OFDM_TAP_RX_METRIC: v = &r->metric; break;
     case OFDM_TAP_RX_PEAKS: v = &r->peaks; break;
+    case ORC_TAP_PEAKS_GR: v = &r->peaks_gr; break;
+    case OFDM_TAP_RX_PRESEL: v = &r->presel; break;
+    case ORC_TAP_RANGES: v = &r->ranges; break;
     case OFDM_TAP_RX_ANGLES: v = &r->angles; break;
     case OFDM_TAP_RX_FRAMES: v = &r->frames; break;
     case OFDM_TAP_RX_FFT: v = &r->fft; break;
@@ -1455,12 +1871,16 @@ int orc_rx_packets(const orc_rx_result *r, uint8_t *payload_out, uint64_t cap, u
 }
 
 void orc_rx_stats(const orc_rx_result *r, ofdm_stats *st) { *st = r->st; }
+uint64_t orc_rx_presel_miss(const orc_rx_result *r) { return r->presel_miss; }
 
 void orc_rx_free(orc_rx_result *r) {
   if (!r) return;
   vec_free(&r->y);
   vec_free(&r->metric);
   vec_free(&r->peaks);
+  vec_free(&r->peaks_gr);
+  vec_free(&r->presel);
+  vec_free(&r->ranges);
   vec_free(&r->angles);
   vec_free(&r->frames);
   vec_free(&r->fft);

@@ -46,6 +46,13 @@ uint64_t orc_rx_payload_bytes(const orc_rx_result *r);
 int orc_rx_packets(const orc_rx_result *r, uint8_t *payload_out, uint64_t cap, uint64_t *off, uint32_t *len,
                    uint8_t *ok, int max_pkts);
 void orc_rx_stats(const orc_rx_result *r, ofdm_stats *st);
+/* oracle-only taps (orc_rx_tap): the flags of gr_peak_detector_fb run LITERALLY (float32 recurrence of the average from
+ * the first sample) -- the cross-check of the normative evaluation; the exact-evaluation range of every tile */
+#define ORC_TAP_PEAKS_GR 100 /* u64[] */
+#define ORC_TAP_RANGES 102   /* i32[ntiles][2] */
+/* samples whose exact metric is above the candidate threshold but which the float32 pre-selection left outside every
+ * range: the normative detector cannot see them.  0 on every input the tests hold (asserted there). */
+uint64_t orc_rx_presel_miss(const orc_rx_result *r);
 void orc_rx_free(orc_rx_result *r);
 
 /* spectrum sensor (predictive_sense.py:72-123,150-268); outputs may be NULL */

@@ -67,6 +67,8 @@ def lib():
         L.orc_rx_stats.argtypes = [vp, C.POINTER(_abi.ofdm_stats)]
         L.orc_rx_stats.restype = None
         L.orc_rx_free.argtypes = [vp]
+        L.orc_rx_presel_miss.restype = C.c_uint64
+        L.orc_rx_presel_miss.argtypes = [vp]
         SC = C.POINTER(_abi.ofdm_sense_cfg)
         L.orc_sense_count.argtypes = [SC, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.orc_sense.argtypes = [SC, vp, C.c_uint64, vp, vp, vp, vp]
@@ -200,7 +202,13 @@ _TAP_DTYPES = {
     _abi.TAP_RX_ANGLES: np.float32, _abi.TAP_RX_FRAMES: np.uint64, _abi.TAP_RX_FFT: np.complex64,
     _abi.TAP_RX_ACQ: np.complex64, _abi.TAP_RX_SINK: np.complex64, _abi.TAP_RX_PACKETS: np.uint8,
     _abi.TAP_RX_SAMPLER: np.complex64, _abi.TAP_RX_SIGMIX: np.complex64, _abi.TAP_RX_NCO: np.complex64,
+    _abi.TAP_RX_PRESEL: np.float32,
 }
+# oracle-only taps: the literal float32-recurrence detector's flags (cross-check of the normative evaluation) and the
+# exact-evaluation range of every 2048-sample tile
+TAP_PEAKS_GR, TAP_RANGES = 100, 102
+_TAP_DTYPES[TAP_PEAKS_GR] = np.uint64
+_TAP_DTYPES[TAP_RANGES] = np.int32
 
 
 class RxResult(object):
@@ -211,6 +219,8 @@ class RxResult(object):
         st = _abi.ofdm_stats()
         lib().orc_rx_stats(self._h, C.byref(st))
         self.stats = st.as_dict()
+        # samples above the candidate threshold that the float32 pre-selection left outside every range (expected: 0)
+        self.presel_miss = int(lib().orc_rx_presel_miss(self._h))
         np_ = lib().orc_rx_npackets(self._h)
         nb = lib().orc_rx_payload_bytes(self._h)
         pay = np.zeros(max(nb, 1), np.uint8)
@@ -227,7 +237,7 @@ class RxResult(object):
         out = np.zeros(nb // dt.itemsize, dt)
         if nb:
             lib().orc_rx_tap(self._h, tap, _ptr(out), nb)
-        if tap == _abi.TAP_RX_FRAMES:
+        if tap in (_abi.TAP_RX_FRAMES, TAP_RANGES):
             out = out.reshape(-1, 2)
         elif tap in (_abi.TAP_RX_FFT, _abi.TAP_RX_SAMPLER):
             out = out.reshape(-1, self._cfg.fft_length)

@@ -13,7 +13,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 maps = [b["carrier_map"] for b in json.load(open(os.path.join(ROOT, "tests/golden/sense_blocks.json")))["blocks"]]
 t_end = time.time() + budget
-ncase = nbad = 0
+ncase = nbad = nlit = nmiss = 0
 while time.time() < t_end:
     N = int(rng.choice([64, 128, 256, 512, 512, 512, 1024, 2048, 4096]))
     # multiples of 4 and, now and then, of 2: partial-nibble carrier maps (mapper and sink index rules differ)
@@ -91,7 +91,7 @@ while time.time() < t_end:
             a, b = (0, len(x)) if rng.random() < 0.5 else sorted(rng.integers(0, len(x), 2).tolist())
             x[a:b] += (amp * np.exp(2j * np.pi * rng.uniform(-0.5, 0.5) * np.arange(b - a))).astype(np.complex64)
             desc["carrier"] = [amp, int(a), int(b)]
-        taps = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_SAMPLER, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK,
+        taps = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_PRESEL, _abi.TAP_RX_SAMPLER, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK,
                 _abi.TAP_RX_PACKETS)
         mask = 0
         for t in taps:
@@ -108,6 +108,9 @@ while time.time() < t_end:
                 w = u[max(0, q0 - 6):q0 + 7]
                 print("   u around %d (in gpu: %s, in oracle: %s): %s" % (q0, q0 in pg, q0 in po, np.array2string(w, precision=7)))
         assert pg == po, "peaks"
+        if po != ro.tap(orc.TAP_PEAKS_GR).tolist():
+            nlit += 1          # (the literal float32 recurrence differs: a marginal run, both sides the same)
+        nmiss += 1 if ro.presel_miss else 0
         assert eng.tap(_abi.TAP_RX_FRAMES).tolist() == ro.tap(_abi.TAP_RX_FRAMES).tolist(), "frames"
         yg, yo = eng.tap(_abi.TAP_RX_CHAN_FILT), ro.tap(_abi.TAP_RX_CHAN_FILT)
         if not np.array_equal(yg, yo):
@@ -116,6 +119,7 @@ while time.time() < t_end:
                 len(bad), len(yo), bad[:8].tolist(), yg[bad[:3]], yo[bad[:3]], x[bad[:3]]))
         assert np.array_equal(yg, yo), "chan_filt"
         assert np.array_equal(eng.tap(_abi.TAP_RX_METRIC), ro.tap(_abi.TAP_RX_METRIC)), "metric"
+        assert np.array_equal(eng.tap(_abi.TAP_RX_PRESEL), ro.tap(_abi.TAP_RX_PRESEL), equal_nan=True), "presel"
         assert np.array_equal(eng.tap(_abi.TAP_RX_ANGLES), ro.tap(_abi.TAP_RX_ANGLES)), "angles"
         for k in ("symbols", "peaks", "frames"):
             assert eng.last_stats[k] == ro.stats[k], k
@@ -137,4 +141,5 @@ while time.time() < t_end:
         print("MISMATCH [%s]" % (e if isinstance(e, AssertionError) else "error " + str(e)[:80]), json.dumps(desc), flush=True)
     finally:
         eng.close()
-print("fuzz: %d cases, %d mismatches, seed %d" % (ncase, nbad, seed))
+print("fuzz: %d cases, %d mismatches, seed %d (captures on which the literal recurrence differs: %d; with a pre-selection miss: %d)" % (
+    ncase, nbad, seed, nlit, nmiss))

@@ -10,7 +10,7 @@ symbols, derotated symbols -- is compared with array_equal."""
 import numpy as np
 import pytest
 
-from helpers import loopback_stream, make_cfg, make_payloads
+from helpers import MARGINAL, loopback_stream, make_cfg, make_payloads, marginal_capture
 from ofdm_uhd_amd import _abi, config
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +29,7 @@ CASES = [
     ("qpsk", 512, 200, 128, 1026, 4, 30.0, 1.3),      # coarse offset +1 bin
     ("qpsk", 512, 200, 128, 1026, 4, 30.0, -2.4),     # coarse offset -2 bins
 ]
-RX_TAPS = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK,
+RX_TAPS = (_abi.TAP_RX_CHAN_FILT, _abi.TAP_RX_METRIC, _abi.TAP_RX_PRESEL, _abi.TAP_RX_FFT, _abi.TAP_RX_ACQ, _abi.TAP_RX_SINK,
            _abi.TAP_RX_PACKETS)
 
 
@@ -93,6 +93,9 @@ def _check_rx(orc, cfg, eng, x):
     # bit-identical by construction
     assert np.array_equal(eng.tap(_abi.TAP_RX_CHAN_FILT), ro.tap(_abi.TAP_RX_CHAN_FILT))
     assert np.array_equal(eng.tap(_abi.TAP_RX_METRIC), ro.tap(_abi.TAP_RX_METRIC))
+    # the float32 pre-selection of the metric (it picks the ranges of the fixed-point evaluation and feeds the peak
+    # detector's average outside them: a defined schedule) -- the same bits
+    assert np.array_equal(eng.tap(_abi.TAP_RX_PRESEL), ro.tap(_abi.TAP_RX_PRESEL))
     # complex_to_arg is evaluated with the same float32 operations on both sides: the NCO's input is exact
     assert np.array_equal(eng.tap(_abi.TAP_RX_ANGLES), ro.tap(_abi.TAP_RX_ANGLES))
     # FFT output, equalised carriers (all occ of them, also the ones the map leaves empty) and the frame
@@ -276,6 +279,33 @@ def test_set_carrier_map_live(orc):
     assert np.array_equal(eng.tx(pay), a0)
     eng.close()
     ref.close()
+
+
+# The four captures of the round-2 soaks (profiles/r02_soak.txt runs C, D, F: fuzz_parity seeds 3, 7, 13) in which engine
+# and oracle raised different numbers of timing flags: a comparison u > avg * rise inside the rounding noise of the
+# peak detector's running average, which the oracle ran as a float32 recurrence and the engine as a closed form.
+# Regenerated from the seeds by tests/soak/find_marginal.py.  The average now has ONE normative evaluation that both
+# sides perform, so these captures -- non-default thresholds, where u drifts across avg * rise
+# slowly -- must agree flag for flag like every other; gr_peak_detector_fb run literally (the float32 recurrence from
+# the first sample, ORC_TAP_PEAKS_GR) still differs on them by that one marginal run, which is what makes them the
+# regression cases.
+@pytest.mark.parametrize("which", range(len(MARGINAL)))
+def test_marginal_detector_cases(orc, which):
+    d = MARGINAL[which]
+    cfg, x = marginal_capture(orc, d)
+    eng = _engine(cfg)
+    _check_rx(orc, cfg, eng, x)                      # every tap, flags and packets identical -- with the taps on ...
+    flags_taps = eng.tap(_abi.TAP_RX_PEAKS).tolist()
+    eng.set_taps()
+    pk = eng.rx(x)                                   # ... and without: the taps change nothing the detector sees
+    ro = orc.rx(cfg, x, 0)
+    flags = eng.tap(_abi.TAP_RX_PEAKS).tolist()
+    assert flags == flags_taps == ro.tap(_abi.TAP_RX_PEAKS).tolist() and pk == ro.packets
+    assert len(flags) == d["flags"]
+    # what makes the capture marginal: the literal float32 recurrence decides one run the other way
+    lit = ro.tap(orc.TAP_PEAKS_GR).tolist()
+    assert len(lit) == d["literal"] and sorted(set(lit) ^ set(flags))[0] == d["at"]
+    eng.close()
 
 
 def test_capture_without_flags(orc):
