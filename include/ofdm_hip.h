@@ -283,7 +283,10 @@ int ofdm_rx_set_origin(ofdm_handle *h, uint64_t first_sample_index);
  * the receiver's input stage (the wait for the transmit batch that fills iq, the channel filter) and returns at
  * once; an ofdm_tx_async issued next is queued behind that stage only -- it may refill the same iq buffer -- and runs
  * while the following ofdm_rx(h, iq, nsamples, ...) (same arguments: it picks the submitted stage up) is busy with
- * its own kernels and host round trips.  Optional: ofdm_rx alone does the same work in order. */
+ * its own kernels and host round trips.  Optional: ofdm_rx alone does the same work in order.
+ * Exception: with OFDM_SYNC_FIXED (chan_filt is the input itself) or a fused sensor (ofdm_set_rx_sense) the receiver
+ * reads iq until the end of ofdm_rx; between ofdm_rx_submit and that ofdm_rx a transmit call whose iq_out overlaps
+ * the submitted buffer is refused with OFDM_E_INVAL (transmit into another buffer, or after ofdm_rx). */
 int ofdm_rx_submit(ofdm_handle *h, const ofdm_c32 *iq, uint64_t nsamples);
 int ofdm_rx_packet_pos(ofdm_handle *h, uint64_t *pos, int cap, int *n);
 int ofdm_rx_nco_state(ofdm_handle *h, uint64_t *flags, uint64_t *phase, double *step, uint8_t *swallowed,

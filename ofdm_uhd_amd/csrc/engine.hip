@@ -1,6 +1,7 @@
 // engine.hip -- libofdm_hip.so: handle, workspaces and the C ABI of include/ofdm_hip.h.
 // gfx950 (MI355X) only.  Build: see Makefile (hipcc --offload-arch=gfx950 -ffp-contract=off).
 #include <math.h>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 
@@ -261,6 +262,9 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   if (occ < 16) FAIL(h, OFDM_E_INVAL, "occupied_tones < 16");
   if (CP < 1 || CP > N) FAIL(h, OFDM_E_INVAL, "cp_length must be in [1, fft_length]");
   if (cfg->arity < 2 || cfg->arity > OFDM_MAX_ARITY) FAIL(h, OFDM_E_INVAL, "arity must be in [2, 256]");
+  for (uint32_t i = 0; i < cfg->arity; i++)
+    if (!std::isfinite(cfg->constellation[i].re) || !std::isfinite(cfg->constellation[i].im))
+      FAIL(h, OFDM_E_INVAL, "constellation points must be finite");
   if (cfg->ntaps < 1 || cfg->ntaps > OFDM_MAX_TAPS) FAIL(h, OFDM_E_INVAL, "ntaps must be in [1, 512]");
   if (cfg->whitener_offset > 15) FAIL(h, OFDM_E_INVAL, "whitener_offset must be between 0 and 15, inclusive");
   // (alpha <= 0.25: the closed form of the detector's running average carries weights decay^-2048 in float64)
@@ -365,13 +369,25 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
       float amax = 0.f;
       for (uint32_t i = 0; i < cfg->arity && ok; i++) {
         const float re = cfg->constellation[i].re, im = cfg->constellation[i].im;
-        if (!(re == re) || !(im == im)) ok = false;
         const size_t a = std::lower_bound(lr.begin(), lr.end(), re) - lr.begin();
         const size_t b = std::lower_bound(li.begin(), li.end(), im) - li.begin();
         const size_t cell = a * li.size() + b;
-        if (seen[cell]++) ok = false;
+        if (cell >= seen.size() || seen[cell]++) {
+          ok = false;
+          break;
+        }
         g.idx[cell] = (uint8_t)i;
         amax = fmaxf(amax, fmaxf(fabsf(re), fabsf(im)));
+      }
+      // The four bracketing points hold the full search's first minimum only while a step between neighbouring levels
+      // is not absorbed by the rounding of |x - pos|^2 at the edge of the slicer's range (bound = 64 amax, beyond
+      // which the full search runs): smallest spacing^2 above the float32 ulp of 2 bound^2.
+      if (ok) {
+        float dmin = INFINITY;
+        for (size_t a = 1; a < lr.size(); a++) dmin = fminf(dmin, lr[a] - lr[a - 1]);
+        for (size_t b = 1; b < li.size(); b++) dmin = fminf(dmin, li[b] - li[b - 1]);
+        const float bnd = 64.0f * amax;
+        if (!(dmin * dmin > 2.0f * bnd * bnd * 1.1920929e-7f)) ok = false;
       }
       g.nr = (int)lr.size();
       g.ni = (int)li.size();
@@ -705,6 +721,14 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
   if (total == 0) return OFDM_OK;
   if (!iq_out) FAIL(h, OFDM_E_INVAL, "null iq_out");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  // A submitted receive stage that reads its input to the end of the call (SYNC "fixed", fused sensing) has recorded
+  // no event this batch could wait on: refilling THAT buffer now would race with the receiver.
+  if (h->rx.sub_hold && h->rx.sub_valid) {
+    const uintptr_t a0 = (uintptr_t)iq_out, a1 = a0 + total * sizeof(c32);
+    const uintptr_t b0 = (uintptr_t)h->rx.sub_iq, b1 = b0 + h->rx.sub_n * sizeof(c32);
+    if (a0 < b1 && b0 < a1)
+      FAIL(h, OFDM_E_INVAL, "ofdm_tx into the buffer of a submitted ofdm_rx that reads it to the end of the call (SYNC fixed / fused sensing): call ofdm_rx first");
+  }
   // the receiver may still be reading the buffer this batch writes (ofdm_rx_submit / ofdm_rx in flight)
   if (h->rx_in_pending && h->txs != h->stream) HIPCHK(h, hipStreamWaitEvent(h->txs, h->ev_rx_in, 0));
 
@@ -795,7 +819,10 @@ extern "C" int ofdm_channel(ofdm_handle* h, ofdm_c32* iq, uint64_t n, const ofdm
   if (n == 0) return OFDM_OK;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   c32* d = reinterpret_cast<c32*>(iq);
+  // a transmit batch still in flight (ofdm_tx_async) may be using the staging buffer, or writing the caller's
+  if (h->tx_pending && h->txs != h->stream) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_tx_done, 0));
   if (!h->dev_ptrs) {
+    if (h->tx_pending && h->txs != h->stream) HIPCHK(h, hipStreamSynchronize(h->txs));  // (ensure() may reallocate it)
     HIPCHK(h, h->d_iq_stage.ensure(n * sizeof(c32)));
     d = h->d_iq_stage.as<c32>();
     HIPCHK(h, hipMemcpyAsync(d, iq, n * sizeof(c32), hipMemcpyHostToDevice, h->stream));

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from helpers import loopback_stream, make_cfg, make_payloads
-from ofdm_uhd_amd import _abi
+from ofdm_uhd_amd import _abi, config
 
 pytestmark = pytest.mark.gpu
 
@@ -226,3 +226,92 @@ def test_metric_above_threshold_everywhere(orc):
     assert got == ro.packets and eng.last_stats["peaks"] == ro.stats["peaks"]
     assert sum(ok for ok, _ in got) >= 6   # (the first burst whole; after the tone the detector average decides, as in the oracle)
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["fixed", "sense"])
+def test_submit_holds_buffer_when_input_is_read_to_the_end(mode):
+    """SYNC 'fixed' (chan_filt IS the input) and fused sensing read the IQ buffer until the end of ofdm_rx: between
+    ofdm_rx_submit and that ofdm_rx a transmit batch into the same buffer is refused (it used to be queued
+    and overwrote the samples under the receiver); into a second buffer it is accepted, and alternating two buffers
+    gives every batch exactly as the calls made one after the other do."""
+    import torch
+    from ofdm_uhd_amd import options
+    from ofdm_uhd_amd.engine import pack_payloads
+    dev = torch.device("cuda:0")
+    N, CP = 512, 128
+    if mode == "fixed":
+        probe = _engine(make_cfg("qpsk", device_ptrs=True))
+        nsym1, _ = probe.tx_frame_count(np.full(1, 500, np.uint32))
+        probe.close()
+        opt = options.default_options(modulation="qpsk", fft_length=N, occupied_tones=200, cp_length=CP, sync="fixed",
+                                      sync_nsymbols=int(nsym1), sync_freq_offset=0.0)
+        cfg = config.make_cfg(opt, device_ptrs=True)
+        lead, tail = 0, 2 * N
+    else:
+        cfg = make_cfg("qpsk", device_ptrs=True)
+        lead, tail = 2 * N, (N + CP) + 2 * N
+    e = _engine(cfg)
+    e.set_channel(sigma=0.002, lead=lead, tail=tail)
+    if mode == "sense":
+        e.set_rx_sense(config.make_sense_cfg(256, 1, 6, 3, 1, threshold=0.05))
+    batches = []
+    for b in range(4):
+        pay = make_payloads(48, 500, seed=70 + b)        # DIFFERENT payloads per batch: an overwrite would show
+        blob, offs, lens = pack_payloads(pay)
+        batches.append((pay, torch.from_numpy(blob.copy()).to(dev), offs, lens))
+    _, nsamp = e.tx_frame_count(batches[0][3])
+    bufs = [torch.empty(nsamp * 2, dtype=torch.float32, device=dev) for _ in range(2)]
+    d_pay = torch.empty(48 * 600, dtype=torch.uint8, device=dev)
+
+    def unpack(npk, off, ln, ok):
+        out = d_pay.cpu().numpy()
+        return [(bool(ok[i]), out[int(off[i]):int(off[i]) + int(ln[i])].tobytes()) for i in range(npk)]
+
+    seq = []
+    for pay, d_blob, offs, lens in batches:
+        n = e.tx_device(d_blob.data_ptr(), offs, lens, bufs[0].data_ptr(), nsamp)
+        seq.append(unpack(*e.rx_device(bufs[0].data_ptr(), n, d_pay.data_ptr(), d_pay.numel(), 100)))
+        assert [p for ok, p in seq[-1] if ok] == pay
+    # pipelined over two buffers
+    pip = []
+    n = e.tx_device(batches[0][1].data_ptr(), batches[0][2], batches[0][3], bufs[0].data_ptr(), nsamp, wait=False)
+    for i in range(4):
+        cur, nxt = bufs[i & 1], bufs[(i + 1) & 1]
+        e.rx_submit_device(cur.data_ptr(), n)
+        if i + 1 < 4:
+            _, d_blob, offs, lens = batches[i + 1]
+            with pytest.raises(ValueError):               # the submitted buffer is still the receiver's
+                e.tx_device(d_blob.data_ptr(), offs, lens, cur.data_ptr(), nsamp, wait=False)
+            n_next = e.tx_device(d_blob.data_ptr(), offs, lens, nxt.data_ptr(), nsamp, wait=False)
+        pip.append(unpack(*e.rx_device(cur.data_ptr(), n, d_pay.data_ptr(), d_pay.numel(), 100)))
+        n = n_next
+    e.wait()
+    assert pip == seq
+    # after ofdm_rx the buffer is free again
+    e.tx_device(batches[0][1].data_ptr(), batches[0][2], batches[0][3], bufs[1].data_ptr(), nsamp)
+    e.close()
+
+
+def test_tx_taps_right_after_async_tx(orc):
+    """ofdm_tap orders itself behind the transmit stream too (it drained only the receive stream, so the TX
+    taps could be copied while k_frame_pack / k_tx_mod were still writing them)."""
+    import torch
+    from ofdm_uhd_amd.engine import pack_payloads
+    cfg = make_cfg("qpsk", device_ptrs=True)
+    dev = torch.device("cuda:0")
+    e = _engine(cfg)
+    e.set_taps(_abi.TAP_TX_FREQ, _abi.TAP_TX_IFFT, _abi.TAP_TX_MAPPER)
+    pay = make_payloads(2048, 1026, seed=9)
+    blob, offs, lens = pack_payloads(pay)
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    _, nsamp = e.tx_frame_count(lens)
+    d_iq = torch.empty(nsamp * 2, dtype=torch.float32, device=dev)
+    e.tx_device(d_blob.data_ptr(), offs, lens, d_iq.data_ptr(), nsamp, wait=False)
+    framed = e.tap(_abi.TAP_TX_PACKETS)                   # no wait() in between
+    freq = e.tap(_abi.TAP_TX_FREQ)
+    ref = [orc.make_packet(make_cfg("qpsk"), p) for p in pay]
+    assert framed.tobytes() == b"".join(ref)
+    _, freq_o, _ = orc.tx(make_cfg("qpsk"), pay[:8], want_taps=True)
+    assert np.array_equal(freq[:len(freq_o)], freq_o)
+    e.wait()
+    e.close()
