@@ -337,7 +337,8 @@ enum {
   OFDM_K_SENSE = 7, /* windowed FFT + |.|^2 + max-hold (+ decision tail)    */
   OFDM_K_FILTER = 8, /* channel filter (overlap-save transforms, streaming)  */
   OFDM_K_EXACT = 9,  /* fixed-point metric + candidates where the pre-selection fired */
-  OFDM_K_COUNT = 10
+  OFDM_K_FRONT = 10, /* fused front end: channel filter + float32 pre-selection in one pass (replaces FILTER + SYNC) */
+  OFDM_K_COUNT = 11
 };
 int ofdm_prof_enable(ofdm_handle *h, int on);
 int ofdm_prof_reset(ofdm_handle *h);

@@ -30,7 +30,7 @@ OFDM_F_PAD_FOR_USRP = 1 << 1
  TAP_RX_SIGMIX, TAP_RX_NCO, TAP_RX_PRESEL, TAP_COUNT) = range(18)
 SYNC_PN, SYNC_FIXED = 0, 1
 
-(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_EXACT, K_COUNT) = range(11)
+(K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_EXACT, K_FRONT, K_COUNT) = range(12)
 OFDM_SENSE_MAX_FFT = 4096
 
 

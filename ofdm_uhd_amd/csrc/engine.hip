@@ -229,7 +229,7 @@ extern "C" const char* ofdm_last_error(const ofdm_handle* h) { return h ? h->err
 
 extern "C" const char* ofdm_kernel_name(int k) {
   static const char* names[OFDM_K_COUNT] = {"k_frame_pack", "k_tx_mod",   "k_channel", "k_sync",
-                                            "k_peak",       "k_rx_demod", "k_deframe", "k_sense",   "k_chan_filter", "k_sync_exact"};
+                                            "k_peak",       "k_rx_demod", "k_deframe", "k_sense",   "k_chan_filter", "k_sync_exact", "k_front"};
   return (k >= 0 && k < OFDM_K_COUNT) ? names[k] : "?";
 }
 

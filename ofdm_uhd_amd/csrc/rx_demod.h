@@ -981,6 +981,7 @@ struct RxState {
   const c32* y_ptr = nullptr;  // chan_filt's output of the last call: rx.y, or the input itself (SYNC "fixed")
   // ofdm_rx_submit: the input stage of the next ofdm_rx call is already queued for this buffer
   bool sub_valid = false, in_event_at_end = false;
+  bool front_done = false;  // the fused front end (filter + pre-selection) of the pending call has been queued
   bool sub_hold = false;  // a submitted input stage whose buffer stays in use until the end of the ofdm_rx that picks it up
   const void* sub_iq = nullptr;
   uint64_t sub_n = 0;

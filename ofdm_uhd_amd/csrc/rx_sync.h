@@ -210,6 +210,36 @@ __host__ __device__ inline SyncLds sync_lds_layout(int R, int HM) {
   l.total = o;
   return l;
 }
+// LDS of the fused front end (k_sync<W, true, F>: channel filter + metric): [history | tile | carry] of filtered
+// samples (carry: what the tile's last filter block produces beyond the tile's end, at most B - 1 samples) | the
+// transforms' scratch, which the tile's M values (mt) take over between the filter phase and the next one | the M
+// history, double-buffered (the next tile's is written while this tile's is still being read) | scan / vote scratch.
+struct FrontLds {
+  size_t ys, mt, mh0, mh1, tw, misc, total;
+  int C;
+};
+__host__ __device__ inline FrontLds front_lds_layout(int R, int HM, int B, int F) {
+  FrontLds l;
+  l.C = (B + 7) / 8 * 8;
+  size_t o = 0;
+  l.ys = o;
+  o += (size_t)(sync_lp(R + l.C) + 2) * sizeof(c32);
+  o = (o + 15) & ~(size_t)15;
+  l.mt = o;
+  const size_t mtb = ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  const size_t scb = (size_t)SYNC_THREADS * 9 * sizeof(c32);  // 256/(F/8) transforms x (F + F/8) points
+  o += mtb > scb ? mtb : scb;
+  l.mh0 = o;
+  o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  l.mh1 = o;
+  o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  l.tw = o;  // the filter transforms' twiddle table (fft.h FftTwLds): registers are what this kernel is short of
+  o += ((size_t)fft_tw_lds_points(F) * sizeof(c32) + 15) & ~(size_t)15;
+  l.misc = o;
+  o += 384;
+  l.total = o;
+  return l;
+}
 // LDS of k_sync_exact: exact M over [amin-CP+1, bmax] (me) | exact u over [amin, bmax] (ue) | scan scratch
 struct ExactLds {
   size_t me, ue, misc, total;
@@ -640,21 +670,34 @@ __device__ __forceinline__ bool sync_finish_tile(const SyncParams& p, const floa
 // values of M before the tile computed by the previous tile's evaluation.  A segment therefore starts one tile early (the
 // warm-up tile: a full evaluation whose M values seed the first owned tile, its u discarded) behind a prologue that
 // loads the 2D samples of history -- any segmentation of the stream gives the same bits.
-template <int W, bool STATIC>
-__global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
+// F > 0: the FUSED front end -- the channel filter (k_chan_filter's overlap-save blocks, same transforms, same bits) runs
+// inside this kernel: the filter blocks whose first output lies in a tile are transformed by the workgroup right before
+// that tile's metric, their outputs going to HBM (y, for the demodulator and k_sync_exact) AND straight into the LDS
+// window the metric reads -- the filtered stream is written once and not read back here (5.3 KB per symbol of HBM reads
+// at C2).  A thread keeps its place in its filter block: twiddles and its bins of the transformed taps stay in registers
+// across the metric phases; the next block's input window is in flight while the metric runs.  Only a segment's owner
+// stores y (the prologue and the warm-up tile recompute what they need: blocks lie on the capture's grid, so the
+// values are the same).  Needs the fixed LDS layout with history + carry no longer than a tile, and F <= 512 (a
+// transform's threads inside one wave).
+template <int W, bool STATIC, int F = 0>
+__global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p, FilterParams fp) {
 #ifdef SYNC_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
+  constexpr bool FUSED = F > 0;
+  static_assert(!FUSED || (STATIC && F <= 512), "the fused front end uses the fixed LDS layout and wave-sized transforms");
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   constexpr int T = SYNC_TILE;
   const int R = p.R;
-  const SyncLds L = sync_lds_layout(R, p.HM);
-  c32* ys = reinterpret_cast<c32*>(smem + L.ys);
-  float* mh = reinterpret_cast<float*>(smem + L.mh);
-  float* mt = reinterpret_cast<float*>(smem + L.mt);
-  unsigned char* misc = smem + L.misc;
+  const SyncLds L0 = sync_lds_layout(R, p.HM);
+  const FrontLds L1 = front_lds_layout(R, p.HM, FUSED ? fp.B : 8, FUSED ? F : 64);
+  c32* ys = reinterpret_cast<c32*>(smem + (FUSED ? L1.ys : L0.ys));
+  float* mh = reinterpret_cast<float*>(smem + (FUSED ? L1.mh0 : L0.mh));
+  float* mh_nxt = reinterpret_cast<float*>(smem + (FUSED ? L1.mh1 : L0.mh));  // (fused: the next tile's M history)
+  float* mt = reinterpret_cast<float*>(smem + (FUSED ? L1.mt : L0.mt));
+  unsigned char* misc = smem + (FUSED ? L1.misc : L0.misc);
   float* scA = reinterpret_cast<float*>(misc);                 // 24 floats
   float* scB = reinterpret_cast<float*>(misc + 96);            // 8 floats
 
@@ -665,11 +708,93 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
   const uint64_t tile_first = seg > 0 ? tile_own0 - 1 : tile_own0;
   const int D = p.D, CP = p.CP, HM = p.HM;
   const float inv_cp = 1.0f / (float)CP;
+  const int H = R - T;                                     // history samples in front of a tile (>= 2D)
+
+  // ---- the filter's side of the fused kernel ----------------------------------------------------------------
+  // A tile needs at most two rounds of the workgroup's BPR blocks (B > F/2: fewer than 2 BPR blocks start in 2048
+  // samples), so a thread keeps TWO input windows in registers across the metric phase -- fetched a whole tile ahead,
+  // which is what hides HBM's loaded latency with only three workgroups per CU.  The twiddles come from a table in LDS
+  // and the thread's bins of the transformed taps are re-read (L1 / L2) at the start of every filter phase, BEFORE the
+  // prefetch in program order: nothing else may stay in registers over the metric phase at this budget.
+  constexpr int FF = FUSED ? F : 64;      // (a legal length for the unfused instantiation's dead code)
+  constexpr int TF = FF / 8;              // threads per filter block
+  constexpr int BPR = SYNC_THREADS / TF;  // blocks per round of the workgroup
+  const int fg = tid / TF, ft = tid % TF;
+  c32* fsc = reinterpret_cast<c32*>(mt) + fg * fft_lds_points(FF);  // this block's transform scratch (overlays mt)
+  c32* twl = reinterpret_cast<c32*>(smem + L1.tw);
+  c32 xna[8], xnb[8];
+  const int64_t own_lo = (int64_t)(tile_own0 * (uint64_t)T);
+  const int64_t own_hi = (int64_t)((tile_own1 * (uint64_t)T < p.nsamples) ? tile_own1 * (uint64_t)T : p.nsamples);
+  // first block with its first output at or behind sample n >= 0 (block b starts at b*B - goff)
+  auto blk_at = [&](uint64_t n) -> int64_t { return (int64_t)((n + (uint64_t)fp.goff + (uint64_t)fp.B - 1) / (uint64_t)fp.B); };
+  auto load_window = [&](c32 (&w)[8], int64_t b) {
+    const int64_t x0 = b * fp.B - fp.goff - fp.ntm1 + ft;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int64_t xi = x0 + m * TF;
+      w[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? fp.x[xi] : mk(0.f, 0.f);
+    }
+  };
+  // one overlap-save block: window -> transform -> x transformed taps -> inverse -> the last B points to HBM (owned
+  // samples) and into the LDS window [history | tile | carry] of the tile that starts at t0s
+  auto do_block = [&](const c32 (&w)[8], const c32 (&Hr)[8], int64_t b, int64_t t0s) {
+    c32 e[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) e[m] = w[m];
+    int tt = ft;  // opaque copy, renewed every block: keeps the transforms' LDS addresses out of the registers
+    asm volatile("" : "+v"(tt));
+    fft_run1<FF, false, FILTER_PK, FftWaveSync, FftTwLds>(e, tt, fsc, FftTwLds{twl}, FftWaveSync());
+#pragma unroll
+    for (int m = 0; m < 8; m++) e[m] = cmul(e[m], Hr[m]);  // volk_32fc_x2_multiply_32fc
+    asm volatile("" : "+v"(tt));
+    fft_run1<FF, true, FILTER_PK, FftWaveSync, FftTwLds>(e, tt, fsc, FftTwLds{twl}, FftWaveSync());
+    const int64_t bs = b * fp.B - fp.goff;  // first output of the block
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int idx = ft + m * TF;
+      const int64_t n = bs + (idx - fp.ntm1);
+      const int64_t pos = n - t0s + H;  // place in [history | tile | carry]
+      if (idx >= fp.ntm1 && n >= 0 && pos >= 0) {
+        const bool in = (uint64_t)n < p.nsamples;
+        if (!SYNC_ABLATE(p, 8)) ys[sync_lp((int)pos)] = in ? e[m] : mk(0.f, 0.f);  // (y behind the end of the stream reads as zero)
+        if (n >= own_lo && n < own_hi && !SYNC_ABLATE(p, 4)) fp.y[n] = e[m];
+      }
+    }
+  };
+  auto load_taps = [&](c32 (&Hr)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) Hr[m] = fp.Hf[ft + m * TF];
+  };
+  int64_t bcur = 0;  // next filter block (fused)
 
   // ---- segment prologue: the y history of the first tile walked (y before the stream start reads as zero; so does the
   //      M history, which only the stream's first tile ever uses: a warm-up tile's u is discarded) ----
-  {
-    const int H = R - T;                                   // history samples in front of a tile (>= 2D)
+  if constexpr (FUSED) {
+    for (int i = tid; i < fft_tw_used(FF); i += SYNC_THREADS) twl[lpad(i)] = fp.twF[i];
+    for (int i = tid; i < sync_lp(R + L1.C) + 2; i += SYNC_THREADS) ys[i] = mk(0.f, 0.f);
+    for (int i = tid; i < HM; i += SYNC_THREADS) mh_nxt[sync_lp(i)] = 0.0f;
+    const uint64_t tf0 = tile_first * (uint64_t)T;
+    const int64_t bp0 = tf0 + (uint64_t)fp.goff >= (uint64_t)H ? (int64_t)((tf0 + (uint64_t)fp.goff - (uint64_t)H) / (uint64_t)fp.B) : 0;
+    const int64_t bp1 = blk_at(tf0);
+    __syncthreads();  // (the zero fill and the twiddle table before the prologue's transforms)
+    {
+      // the blocks that cover the history (once per segment: plain loads, no prefetch)
+      c32 Hr[8];
+      load_taps(Hr);
+      for (int64_t bb = bp0; bb < bp1; bb += BPR) {
+        const int64_t b = bb + fg;
+        if (b < bp1) {  // (a transform's threads share the decision: one block = TF consecutive threads)
+          load_window(xna, b);
+          do_block(xna, Hr, b, (int64_t)tf0);
+        }
+      }
+    }
+    bcur = bp1;
+    // the first tile's windows
+    const int64_t be = blk_at(tf0 + T);
+    if (bcur + fg < be) load_window(xna, bcur + fg);
+    if (bcur + BPR + fg < be) load_window(xnb, bcur + BPR + fg);
+  } else {
     const int64_t h0 = (int64_t)(tile_first * (uint64_t)T) - H;
     for (int c = tid; c < H; c += SYNC_THREADS) {
       const int64_t n = h0 + c;
@@ -704,7 +829,29 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     asm volatile("" : "+v"(tl));
     const uint64_t t0 = tile * (uint64_t)T;
     const bool owned = tile >= tile_own0;
+    int ncarry = 0;  // (fused) samples of the next tile this tile's last filter block has produced
 
+    if constexpr (FUSED) {
+      // ---- 1. the filter blocks whose first output lies in this tile: y to HBM and into the LDS window
+      const int64_t b1 = blk_at(t0 + T);
+      {
+        c32 Hr[8];
+        load_taps(Hr);  // (before the prefetch below in program order: its wait must not cover the next tile's windows)
+        const int64_t ba = bcur + fg, bb = bcur + BPR + fg;
+        STAMP_VM(10);  // (diagnostic build: the taps and the windows have arrived)
+        if (ba < b1) do_block(xna, Hr, ba, (int64_t)t0);
+        STAMP(8);
+        if (bb < b1) do_block(xnb, Hr, bb, (int64_t)t0);
+        STAMP(9);
+      }
+      bcur = b1;
+      ncarry = (int)(b1 * fp.B - fp.goff - (int64_t)(t0 + T));
+      if (tile + 1 < tile_own1) {  // the next tile's windows: in flight over this tile's metric phase
+        const int64_t b2 = blk_at(t0 + 2ull * T);
+        if (b1 + fg < b2) load_window(xna, b1 + fg);
+        if (b1 + BPR + fg < b2) load_window(xnb, b1 + BPR + fg);
+      }
+    } else {
     // ---- 1. the tile of y into the ring.  Ring hazards: the slots written hold samples more than HY before this
     //         tile -- every read of them happened before the last barrier of the previous iteration.
     if (have_pre) {
@@ -739,6 +886,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) ypre[r] = src[tl + r * SYNC_THREADS];
       have_pre = true;
+    }
     }
     STAMP(1);
     __syncthreads();  // B2: the tile's y is in the ring
@@ -795,7 +943,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     if constexpr (STATIC) {
       // every read of this tile's y happened before B3: slide the newest R - T samples to the front.  (Source and
       // destination do not overlap, R - T <= T; the next tile's store comes after the barriers below.)
-      for (int c = tl; c < R - T; c += SYNC_THREADS) ys[sync_lp(c)] = ys[sync_lp(T + c)];
+      for (int c = tl; c < R - T + ncarry; c += SYNC_THREADS) ys[sync_lp(c)] = ys[sync_lp(T + c)];
     }
     float Mv[SYNC_V];
     const int mb = sync_lp(SYNC_V * tl);
@@ -847,12 +995,23 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p) {
     }
     float manc = 0.f;
     for (int m = -CP + tl; m < 0; m += SYNC_THREADS) manc += mh[sync_lp(HM + m)];
+    if constexpr (FUSED) {
+      // the CP newest M values become the next tile's history -- into the OTHER history buffer, before B5: behind it mt is
+      // the transforms' scratch again (the next tile's filter phase)
+      for (int i = tl; i < HM; i += SYNC_THREADS) mh_nxt[sync_lp(i)] = mt[sync_lp(T - HM + i)];
+    }
     float mex, mach;
     block_scan1_sum1(msum, manc, scB, &mex, &mach);  // B5
     STAMP(6);
-    // the CP newest M values become the next tile's history (every thread has done its reads of mh
-    // and mt before B5; mt is free from here on)
-    for (int i = tl; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = mt[sync_lp(T - HM + i)];
+    if constexpr (FUSED) {
+      float* sw_ = mh;
+      mh = mh_nxt;
+      mh_nxt = sw_;
+    } else {
+      // the CP newest M values become the next tile's history (every thread has done its reads of mh
+      // and mt before B5; mt is free from here on)
+      for (int i = tl; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = mt[sync_lp(T - HM + i)];
+    }
     // Float32 has lost the window energy where it fell below SYNC_ILL of the largest value the running sums went
     // through since the tile's anchor: such a tile goes to the fixed-point evaluation whole (sync_finish_tile).
     float pmx = fmaxf(anch.c, rinc);
