@@ -202,6 +202,11 @@ int ofdm_rx(ofdm_handle *h, const ofdm_c32 *iq, uint64_t nsamples, uint8_t *payl
             uint32_t *payload_len /* max_pkts, host */, uint8_t *crc_ok /* max_pkts, host */,
             int max_pkts, int *npkt, ofdm_stats *stats /* may be NULL */);
 
+/* digital_ofdm_frame_acquisition::snr() (digital_swig.py:4231-4239, "Return an estimate of the SNR of the channel").
+ * In GNU Radio 3.6.0 the block initialises d_snr_est to 0 in its constructor and no code path ever updates it
+ * [GR-3.6.0, recalled; the reference never calls it]: the accessor returns that constant, and so does this. */
+int ofdm_rx_snr(const ofdm_handle *h, float *snr_est);
+
 /* --- spectrum sensing: the `sensor` flowgraph + sense_loop + hex_conv
  *     (predictive_sense.py:72-123,150-268; same code in sensing_and_tramsmitting*.py) ---
  * stream_to_vector(fft_size) -> fft_vcc(fft_size, True, window) -> complex_to_mag_squared
@@ -317,7 +322,9 @@ enum {
   OFDM_TAP_RX_PRESEL = 16,   /* f32[nsamples]: the float32 pre-selection of the timing metric (engine-internal stage, DESIGN.md
                               * section 2: it picks the ranges the normative metric is evaluated on and feeds the peak
                               * detector's running average outside them); no reference probe point */
-  OFDM_TAP_COUNT = 17
+  OFDM_TAP_RX_DEMAPPED = 17, /* u8[nsym]: 1 where the frame sink demapped the symbol (row of RX_FFT / RX_ACQ / RX_SAMPLER): the rows
+                              * OFDM_TAP_RX_SINK holds, in order.  Needs OFDM_TAP_RX_SINK enabled. */
+  OFDM_TAP_COUNT = 18
 };
 /* SIGMIX / NCO evaluate the NCO's closed form sample by sample over the whole stream; inside the symbols the
  * sampler picks, the receiver itself advances the same phasor by a float64 recurrence: RX_SAMPLER is

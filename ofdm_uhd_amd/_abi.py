@@ -27,7 +27,7 @@ OFDM_F_PAD_FOR_USRP = 1 << 1
 
 (TAP_TX_PACKETS, TAP_TX_FREQ, TAP_RX_CHAN_FILT, TAP_RX_METRIC, TAP_RX_PEAKS, TAP_RX_ANGLES,
  TAP_RX_FRAMES, TAP_RX_FFT, TAP_RX_ACQ, TAP_RX_SINK, TAP_RX_PACKETS, TAP_TX_MAPPER, TAP_TX_IFFT, TAP_RX_SAMPLER,
- TAP_RX_SIGMIX, TAP_RX_NCO, TAP_RX_PRESEL, TAP_COUNT) = range(18)
+ TAP_RX_SIGMIX, TAP_RX_NCO, TAP_RX_PRESEL, TAP_RX_DEMAPPED, TAP_COUNT) = range(19)
 SYNC_PN, SYNC_FIXED = 0, 1
 
 (K_FRAME, K_TX, K_CHAN, K_SYNC, K_PEAK, K_DEMOD, K_DEFRAME, K_SENSE, K_FILTER, K_EXACT, K_FRONT, K_COUNT) = range(12)
@@ -112,7 +112,7 @@ EXPORTS = (
     "ofdm_set_taps", "ofdm_tap", "ofdm_prof_enable", "ofdm_prof_reset", "ofdm_prof_get",
     "ofdm_kernel_name", "ofdm_sense_count", "ofdm_sense", "ofdm_sense_decide", "ofdm_set_rx_sense",
     "ofdm_rx_sense_result", "ofdm_sense_device_msgs", "ofdm_sense_redecide",
-    "ofdm_rx_packet_pos", "ofdm_rx_nco_state", "ofdm_rx_set_flag_history", "ofdm_rx_set_origin", "ofdm_rx_submit",
+    "ofdm_rx_packet_pos", "ofdm_rx_nco_state", "ofdm_rx_set_flag_history", "ofdm_rx_set_origin", "ofdm_rx_submit", "ofdm_rx_snr",
 )
 
 _LIB = None
@@ -160,6 +160,7 @@ def _declare(lib):
     lib.ofdm_rx_packet_pos.argtypes = [H, vp, C.c_int, C.POINTER(C.c_int)]
     lib.ofdm_rx_nco_state.argtypes = [H, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
     lib.ofdm_rx_set_origin.argtypes = [H, C.c_uint64]
+    lib.ofdm_rx_snr.argtypes = [H, C.POINTER(C.c_float)]
     lib.ofdm_rx_submit.argtypes = [H, C.c_void_p, C.c_uint64]
     lib.ofdm_rx_set_flag_history.argtypes = [H, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, C.c_uint64, C.c_double]
     lib.ofdm_sense_device_msgs.argtypes = [H, C.POINTER(C.c_void_p), u64p, u32p]

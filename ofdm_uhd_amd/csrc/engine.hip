@@ -68,6 +68,9 @@ struct ofdm_handle {
   // constant tables
   DevBuf d_const, d_preamble, d_tw, d_bin2car, d_mask, d_crc, d_Hf, d_twF, d_ks, d_smap, d_kd, d_xp8, d_grid, d_synctab;
   bool has_grid = false;  // the constellation is a full grid of levels (QAM tables): constant-time slicer
+  int sign_kind = 0;      // two-level constellations: sign slicer (DemodParams::sign_kind)
+  unsigned char sign_idx[4] = {0, 0, 0, 0};
+  float sign_eps = 0.f, sign_bound = 0.f;
   int filtF = 0;  // transform length of the channel filter (sync_filter_F)
 
   // TX workspaces
@@ -397,6 +400,35 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
     }
     h->has_grid = ok;
     if (ok) HIPCHK(h, upload(h->d_grid, &g, (size_t)1));
+  }
+  {
+    // two-level constellations (psk.py:27-60 bpsk / qpsk with the rotation of ofdm.py:94-101): sign slicer
+    const ofdm_c32* c = cfg->constellation;
+    h->sign_kind = 0;
+    if (cfg->arity == 2 && c[0].im == 0.f && c[1].im == 0.f && c[0].re == -c[1].re && c[0].re != 0.f) {
+      h->sign_kind = 1;
+      h->sign_idx[c[0].re > 0.f ? 1 : 0] = 0;
+      h->sign_idx[c[1].re > 0.f ? 1 : 0] = 1;
+    } else if (cfg->arity == 4) {
+      const float a = fabsf(c[0].re), b = fabsf(c[0].im);
+      bool ok4 = a > 0.f && b > 0.f;
+      int seen = 0;
+      for (int i = 0; i < 4 && ok4; i++) {
+        if (fabsf(c[i].re) != a || fabsf(c[i].im) != b) ok4 = false;
+        const int ix = (c[i].re > 0.f ? 2 : 0) | (c[i].im > 0.f ? 1 : 0);
+        if (seen & (1 << ix)) ok4 = false;
+        seen |= 1 << ix;
+        h->sign_idx[ix] = (unsigned char)i;
+      }
+      if (ok4) h->sign_kind = 2;
+    }
+    if (h->sign_kind) {
+      // margins: the distances of two table entries differ by 4 |level| |part| >= 4 level eps, against a rounding of
+      // about 4 ulp of distances below 2 (bound + level)^2: eps = level / 512, bound = 8 levels -> factor > 200
+      const float lvl = h->sign_kind == 1 ? fabsf(c[0].re) : fminf(fabsf(c[0].re), fabsf(c[0].im));
+      h->sign_eps = lvl * (1.0f / 512.0f);
+      h->sign_bound = 8.0f * fmaxf(fabsf(c[0].re), fabsf(c[0].im));
+    }
   }
   HIPCHK(h, upload(h->d_preamble, pre.data(), pre.size()));
   HIPCHK(h, upload(h->d_tw, tw.data(), tw.size()));

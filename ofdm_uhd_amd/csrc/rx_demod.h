@@ -140,6 +140,14 @@ struct SlicerGrid {
 struct DemodParams {
   int N, CP, L, occ, zl, nmap, nbits, arity, shift;
   float phase_gain, freq_gain, eq_gain;
+  // Sign slicer for the two-level constellations (BPSK on the real axis, QPSK = a symmetric 2 x 2 grid): a point whose
+  // parts lie clear of the decision boundaries (sign_eps) and inside sign_bound has its nearest table entry in the
+  // quadrant / half-plane of its signs, with a margin far above the float32 rounding of the distances the full
+  // search compares -- the full search's answer at two compares.  Points that fail the test take the full search.
+  //   sign_kind 0: none   1: index = sign_idx[re > 0]   2: index = sign_idx[2 (re > 0) + (im > 0)]
+  int sign_kind;
+  unsigned char sign_idx[4];
+  float sign_eps, sign_bound;
   uint64_t nsamples;
   uint32_t j0, nframes, npeaks;  // frames are peaks[j0 .. j0+nframes)
   int tap_mode;                  // 0: optimistic pass over all frames; 1: tap pass over valid frames
@@ -617,7 +625,13 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
         // the full search's answer, at 4 distance evaluations instead of `arity`.
         unsigned best = 0;
         float bestd;
-        if (use_grid && fabsf(sigrot.re) <= grid->bound && fabsf(sigrot.im) <= grid->bound) {
+        const float sre = fabsf(sigrot.re), sim = fabsf(sigrot.im);
+        if (q.sign_kind != 0 && sre > q.sign_eps && sre < q.sign_bound && sim < q.sign_bound &&
+            (q.sign_kind == 1 || sim > q.sign_eps)) {
+          const unsigned ix = (q.sign_kind == 1) ? (sigrot.re > 0.0f ? 1u : 0u)
+                                                 : ((sigrot.re > 0.0f ? 2u : 0u) | (sigrot.im > 0.0f ? 1u : 0u));
+          best = q.sign_idx[ix];
+        } else if (use_grid && sre <= grid->bound && sim <= grid->bound) {
           int ka = 0, kb = 0;
           for (int a = 1; a < grid->nr - 1; a++) ka += (sigrot.re >= grid->lr[a]) ? 1 : 0;
           for (int b = 1; b < grid->ni - 1; b++) kb += (sigrot.im >= grid->li[b]) ? 1 : 0;
@@ -646,8 +660,12 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
         const c32 er = cmul_conj(sigrot, closest);
         are = are + er.re;
         aim = aim + er.im;
-        if (cnorm(sigrot) > 0.001f) {
-          const c32 qq = cdiv(closest, sigrot);
+        const float sden = cnorm(sigrot);
+        if (sden > 0.001f) {
+          // closest / sigrot as conj-product times ONE reciprocal (normative: the oracle does the same)
+          const float sinv = 1.0f / sden;
+          const c32 qq = mk((closest.re * sigrot.re + closest.im * sigrot.im) * sinv,
+                            (closest.im * sigrot.re - closest.re * sigrot.im) * sinv);
           c32 d = dfe[c];
           d.re = d.re + q.eq_gain * (qq.re - d.re);
           d.im = d.im + q.eq_gain * (qq.im - d.im);

@@ -214,6 +214,13 @@ class Engine(object):
         self._check(rc)
         return [(bool(ok[i]), pay[int(off[i]):int(off[i]) + int(ln[i])].tobytes()) for i in range(npk.value)]
 
+    def snr(self):
+        """digital_ofdm_frame_acquisition.snr() (digital_swig.py:4231-4239): GNU Radio 3.6.0 never updates the estimate
+        it initialises to 0."""
+        v = C.c_float(-1.0)
+        self._check(self._lib.ofdm_rx_snr(self._h, C.byref(v)))
+        return float(v.value)
+
     def rx_submit_device(self, iq_ptr, nsamples):
         """Queue the receiver's input stage for this buffer and return at once (ofdm_rx_submit): a tx_device(...,
         wait=False) issued next is held back only until that stage has read the buffer, and runs beside the
@@ -367,7 +374,7 @@ class Engine(object):
         _abi.TAP_RX_FRAMES: np.uint64, _abi.TAP_RX_FFT: np.complex64, _abi.TAP_RX_ACQ: np.complex64,
         _abi.TAP_RX_SINK: np.complex64, _abi.TAP_RX_PACKETS: np.uint8, _abi.TAP_TX_MAPPER: np.complex64,
         _abi.TAP_TX_IFFT: np.complex64, _abi.TAP_RX_SAMPLER: np.complex64, _abi.TAP_RX_SIGMIX: np.complex64,
-        _abi.TAP_RX_NCO: np.complex64, _abi.TAP_RX_PRESEL: np.float32,
+        _abi.TAP_RX_NCO: np.complex64, _abi.TAP_RX_PRESEL: np.float32, _abi.TAP_RX_DEMAPPED: np.uint8,
     }
 
     def tap(self, tap):

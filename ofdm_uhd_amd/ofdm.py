@@ -59,6 +59,11 @@ class ofdm_mod(object):
         if getattr(options, "log", False):
             self._engine.set_taps(engine._abi.TAP_TX_FREQ, engine._abi.TAP_TX_MAPPER, engine._abi.TAP_TX_IFFT)
         self._log = bool(getattr(options, "log", False))
+        if self._log:
+            # gr.file_sink opens its file when the flow graph is built (truncating it) and appends for the life of
+            # the graph (ofdm.py:123-131)
+            for name in ("ofdm_mapper_c.dat", "ofdm_preambles.dat", "ofdm_ifft_c.dat", "ofdm_cp_adder_c.dat"):
+                open(name, "wb").close()
 
     # -- wiring -------------------------------------------------------------------
     def connect(self, sink):
@@ -178,6 +183,11 @@ class ofdm_demod(object):
         if self._log:
             self._engine.set_taps(engine._abi.TAP_RX_FFT, engine._abi.TAP_RX_ACQ, engine._abi.TAP_RX_SINK,
                                   engine._abi.TAP_RX_SAMPLER, engine._abi.TAP_RX_SIGMIX, engine._abi.TAP_RX_NCO)
+            # file sinks: opened (truncated) with the graph, appended to for its life (ofdm_receiver.py~:144-152,
+            # ofdm.py:253-254)
+            for name in self._LOG_FILES.values():
+                open(name, "wb").close()
+        self._log_samples = 0        # samples of the capture the per-sample probe files already hold
         self.n_packets = 0
         self.n_ok = 0
         self._streaming = False      # feed() has data or history pending
@@ -242,6 +252,7 @@ class ofdm_demod(object):
         self._engine.set_flag_history(None)
         self._engine.set_origin(0)
         self._streaming = False
+        self._log_samples = 0
 
     def feed(self, iq, flush=False):
         """Demodulate the next chunk of a continuous capture; returns the packets that became final.
@@ -255,6 +266,8 @@ class ofdm_demod(object):
         base = self._s_abs
         total = base + len(buf)
         horizon = total if flush else total - span           # flags <= horizon are final after this call
+        prev_final = self._s_final
+        ran = False
         out = []
         if len(buf) and horizon > self._s_final:
             eng = self._engine
@@ -267,6 +280,7 @@ class ofdm_demod(object):
                                  trust_after=self._s_final - base, pred=(pred[0] - base, pred[1], pred[2]))
             eng.set_origin(base)
             pkts = eng.rx(buf)
+            ran = True
             pos = eng.rx_packet_pos().astype(np.int64) + base
             for (ok, payload), p in zip(pkts, pos):
                 if self._s_final < p <= horizon:
@@ -276,6 +290,8 @@ class ofdm_demod(object):
             for j in np.flatnonzero((fl > self._s_final) & (fl <= horizon)):
                 self._s_hist.append((int(fl[j]), int(phi[j]), float(st[j]), int(sw[j])))
             self._s_final = max(self._s_final, horizon)
+        if self._log and ran:
+            self._write_logs(base=base, prev_final=prev_final, horizon=horizon, end=total if flush else None)
         if flush:
             self.reset_stream()
         else:
@@ -288,8 +304,6 @@ class ofdm_demod(object):
             keep = [f for f in self._s_hist if f[0] >= max(start, 1)]
             older = [f for f in self._s_hist if f[0] < max(start, 1)]
             self._s_hist = older[-1:] + keep
-        if self._log:
-            self._write_logs()
         for ok, payload in out:
             self.n_packets += 1
             if ok:
@@ -309,16 +323,58 @@ class ofdm_demod(object):
     def last_stats(self):
         return dict(self._engine.last_stats)
 
-    def _write_logs(self):
+    _LOG_FILES = {"chan_filt": "ofdm_receiver-chan_filt_c.dat", "fft": "ofdm_receiver-fft_out_c.dat",
+                  "acq": "ofdm_receiver-frame_acq_c.dat", "sampler": "ofdm_receiver-sampler_c.dat",
+                  "sigmix": "ofdm_receiver-sigmix_c.dat", "nco": "ofdm_receiver-nco_c.dat", "sink": "ofdm_frame_sink_c.dat"}
+
+    def _write_logs(self, base=None, prev_final=None, horizon=None, end=None):
+        """The reference's --log probe files (ofdm_receiver.py~:144-152, ofdm.py:253-254): appended to for the life of
+        the receiver, like its gr.file_sink blocks.  A one-shot work() appends the whole call.  In a chunked stream
+        (feed) every call re-processes a carried tail: only what became FINAL in this call is appended -- per-sample
+        probes from the last sample written up to the horizon (the NCO behind it still waits for its flags), symbol
+        rows of the frames whose flag lies in (previous horizon, horizon] -- so that the files of a chunked run equal
+        those of one call on the whole capture."""
         A = engine._abi
         e = self._engine
-        iqio.file_sink("ofdm_receiver-chan_filt_c.dat").write(e.tap(A.TAP_RX_CHAN_FILT))
-        iqio.file_sink("ofdm_receiver-fft_out_c.dat").write(e.tap(A.TAP_RX_FFT).reshape(-1))
-        iqio.file_sink("ofdm_receiver-frame_acq_c.dat").write(e.tap(A.TAP_RX_ACQ).reshape(-1))
-        iqio.file_sink("ofdm_receiver-sampler_c.dat").write(e.tap(A.TAP_RX_SAMPLER).reshape(-1))
-        iqio.file_sink("ofdm_receiver-sigmix_c.dat").write(e.tap(A.TAP_RX_SIGMIX))
-        iqio.file_sink("ofdm_receiver-nco_c.dat").write(e.tap(A.TAP_RX_NCO))
-        iqio.file_sink("ofdm_frame_sink_c.dat").write(e.tap(A.TAP_RX_SINK).reshape(-1))
+        F = self._LOG_FILES
+
+        def app(key, arr):
+            iqio.file_sink(F[key], append=True).write(np.ascontiguousarray(arr).reshape(-1))
+
+        y, sm, nco = e.tap(A.TAP_RX_CHAN_FILT), e.tap(A.TAP_RX_SIGMIX), e.tap(A.TAP_RX_NCO)
+        fft, acq, samp, sink = e.tap(A.TAP_RX_FFT), e.tap(A.TAP_RX_ACQ), e.tap(A.TAP_RX_SAMPLER), e.tap(A.TAP_RX_SINK)
+        if base is None:                      # one-shot
+            if not len(sm):                   # (no flag at all: the NCO idles at phase 0, sigmix = chan_filt)
+                sm, nco = y, np.ones(len(y), np.complex64)
+            for key, arr in (("chan_filt", y), ("sigmix", sm), ("nco", nco), ("fft", fft), ("acq", acq),
+                             ("sampler", samp), ("sink", sink)):
+                app(key, arr)
+            return
+        # per-sample probes: absolute samples [log_samples, stop)
+        stop = end if end is not None else max(horizon, self._log_samples)
+        lo, hi = self._log_samples - base, stop - base
+        if hi > lo >= 0:
+            app("chan_filt", y[lo:hi])
+            # (a call that raised no flag at all computes no NCO: phase 0 throughout, sigmix = chan_filt)
+            app("sigmix", sm[lo:hi] if len(sm) else y[lo:hi])
+            app("nco", nco[lo:hi] if len(nco) else np.ones(hi - lo, np.complex64))
+            self._log_samples = stop
+        # symbol rows: frame f of this call holds K[f] + 1 consecutive rows
+        fr = e.tap(A.TAP_RX_FRAMES)
+        if len(fr):
+            rows = np.concatenate([[0], np.cumsum(fr[:, 1].astype(np.int64) + 1)])
+            dem = e.tap(A.TAP_RX_DEMAPPED).astype(bool)
+            sink_row = np.cumsum(dem) - 1         # row of RX_SINK a demapped symbol went to
+            for f in range(len(fr)):
+                p = int(fr[f, 0]) + base
+                if prev_final < p <= horizon:
+                    r0, r1 = int(rows[f]), int(rows[f + 1])
+                    app("fft", fft[r0:r1])
+                    app("acq", acq[r0:r1])
+                    app("sampler", samp[r0:r1])
+                    sel = sink_row[r0:r1][dem[r0:r1]]
+                    if len(sel):
+                        app("sink", sink[sel])
 
     def add_options(normal, expert):
         """

@@ -21,11 +21,14 @@ def streams_of_rank(nstreams, rank, world_size):
     return [s for s in range(nstreams) if s % world_size == rank]
 
 
-def init_process_group(backend=None):
-    """Initialise torch.distributed when launched under torchrun; returns (rank, local_rank, world)."""
+def init_process_group(backend=None, force=False):
+    """Initialise torch.distributed when launched under torchrun -- also with ONE rank (torchrun --nproc-per-node 1
+    sets RANK / MASTER_ADDR: the RCCL communicator and every collective below then really run, on one GPU) -- or when
+    ``force`` is set; returns (rank, local_rank, world).  A plain ``python bench.py`` has no RANK: nothing to set up."""
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if (world > 1 or launched or force) and not dist.is_initialized():
         if backend is None:
             import torch
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -1409,8 +1409,13 @@ static unsigned sink_demapper(frame_sink *s, const ofdm_c32 *in, uint8_t *out, o
       ofdm_c32 e = cmul_conj(sigrot, closest);
       pre[i % (unsigned)T] = pre[i % (unsigned)T] + e.re;
       pim[i % (unsigned)T] = pim[i % (unsigned)T] + e.im;
-      if (cnorm(sigrot) > 0.001f) {
-        ofdm_c32 q = cdiv(closest, sigrot);
+      float sden = cnorm(sigrot);
+      if (sden > 0.001f) {
+        /* pos[bits] / sigrot as the conjugate product times ONE reciprocal (normative; std::complex's own division is
+         * not reproducible across libraries either) */
+        float sinv = 1.0f / sden;
+        ofdm_c32 q = c32((closest.re * sigrot.re + closest.im * sigrot.im) * sinv,
+                         (closest.im * sigrot.re - closest.re * sigrot.im) * sinv);
         s->dfe[i].re = s->dfe[i].re + s->eq_gain * (q.re - s->dfe[i].re);
         s->dfe[i].im = s->dfe[i].im + s->eq_gain * (q.im - s->dfe[i].im);
       }

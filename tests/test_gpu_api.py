@@ -62,3 +62,101 @@ def test_ofdm_mod_demod_objects():
     for i in range(5):
         m.send_pkt(b"packet %d" % i)
     assert np.allclose(m.flush(), iq * 4.0, atol=1e-6)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_path_world_size_1(tmp_path):
+    """The RCCL side of the multi-GPU path on the one GPU a test box has: a fresh child process
+    brings up the "nccl" (= RCCL) process group with WORLD_SIZE=1 before anything touches the GPU, then runs the
+    collectives the bench runs -- reduce_counters, reduce_max -- and the cooperative-sensing exchange on the engine's
+    own device buffer (zero-copy all_reduce(MAX) + ofdm_sense_redecide): with one antenna the fused decisions must be
+    the single-antenna ones."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_ws1.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        from ofdm_uhd_amd import parallel
+        rank, local_rank, world = parallel.init_process_group("nccl")       # before any GPU call
+        import numpy as np, torch
+        import torch.distributed as dist
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+        dev = torch.device("cuda", local_rank)
+        from helpers import make_cfg, make_payloads
+        from ofdm_uhd_amd import config, engine
+        tot = parallel.reduce_counters({"symbols": 22, "packets": 3, "crc_ok": 2, "samples": 14080, "frames": 4, "peaks": 5}, device=dev)
+        tmax = parallel.reduce_max(1.25, device=dev)
+        parallel.barrier()
+        cfg = make_cfg("qpsk")
+        eng = engine.Engine(cfg=cfg)
+        eng.set_channel(sigma=0.003, lead=1024, tail=1664)
+        x = eng.tx(make_payloads(24, 600, seed=5))
+        sc = config.make_sense_cfg(256, 1, 6, 3, 1, threshold=0.05)
+        eng.set_rx_sense(sc)
+        pk = eng.rx(x)
+        single = eng.rx_sense_result(len(x))
+        fused = parallel.allreduce_sensed(eng.sense_device_msgs(), device=dev)   # in place on the engine's buffer
+        torch.cuda.synchronize()
+        eng.sense_redecide()
+        after = eng.rx_sense_result(len(x))
+        print(json.dumps({"tot": tot, "tmax": tmax, "npk": len(pk), "nok": sum(ok for ok, _ in pk),
+                          "hex_same": single["hex"] == after["hex"], "ndec": len(after["hex"]),
+                          "msgs_same": bool(np.array_equal(single["msgs"], after["msgs"])),
+                          "fused_same": bool(np.array_equal(fused.cpu().numpy(), single["msgs"]))}))
+        eng.close()
+        dist.destroy_process_group()
+    """ % (root, root)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["tot"] == {"symbols": 22, "samples": 14080, "packets": 3, "crc_ok": 2, "frames": 4, "peaks": 5}
+    assert res["tmax"] == 1.25 and res["npk"] == 24 and res["nok"] >= 23
+    assert res["ndec"] >= 1 and res["hex_same"] and res["msgs_same"] and res["fused_same"]
+
+
+def test_bench_under_torchrun_one_rank():
+    """bench.py --gpus 1 launched the way the driver launches N > 1 (torch.distributed.run, one rank, RCCL process group
+    up): the same JSON line as the plain launch -- same metric, same work, same recovery."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--packets", "4096", "--cpu-packets", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    a = subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-2000:]
+    ja, jb = json.loads(a.stdout.strip().splitlines()[-1]), json.loads(b.stdout.strip().splitlines()[-1])
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "config", "crc_pass_rate", "crc_ok_payloads_bit_exact"):
+        assert ja[k] == jb[k], k
+    assert jb["n_gpus"] == 1 and jb["crc_ok_payloads_bit_exact"]
+    assert 0.5 < jb["value"] / ja["value"] < 2.0          # (4096-packet steps are launch-bound: loose on purpose)
+
+
+def test_frame_acquisition_snr_accessor():
+    """digital_ofdm_frame_acquisition.snr() (digital_swig.py:4231-4239): GNU Radio 3.6.0 initialises the estimate to 0
+    and never updates it; the ABI carries the accessor with that behaviour."""
+    from ofdm_uhd_amd import engine
+    from helpers import make_cfg
+    e = engine.Engine(cfg=make_cfg("qpsk"))
+    assert e.snr() == 0.0
+    e.close()

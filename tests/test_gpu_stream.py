@@ -113,3 +113,80 @@ def test_feed_after_reset_carrier_map(orc):
         got += s.feed(iq[a:a + 60000])
     got += s.flush()
     assert got == want
+
+
+def _read_logs(dirname):
+    import os
+    out = {}
+    for name in sorted(os.listdir(dirname)):
+        if name.endswith(".dat"):
+            out[name] = np.fromfile(os.path.join(dirname, name), np.complex64)
+    return out
+
+
+RX_LOGS = ("ofdm_receiver-chan_filt_c.dat", "ofdm_receiver-fft_out_c.dat", "ofdm_receiver-frame_acq_c.dat",
+           "ofdm_receiver-sampler_c.dat", "ofdm_receiver-sigmix_c.dat", "ofdm_receiver-nco_c.dat", "ofdm_frame_sink_c.dat")
+TX_LOGS = ("ofdm_mapper_c.dat", "ofdm_preambles.dat", "ofdm_ifft_c.dat", "ofdm_cp_adder_c.dat")
+
+
+def test_log_probe_files_accumulate(orc, tmp_path, monkeypatch):
+    """--log (ofdm.py:123-131,253-254; ofdm_receiver.py~:144-152): the eleven probe files exist, hold the taps' bytes and
+    ACCUMULATE like gr.file_sink does for the life of the flow graph -- across flushes of the modulator, across calls
+    of the demodulator, and across the chunks of a fed stream, whose files equal those of one call on the capture."""
+    import os
+    from ofdm_uhd_amd import _abi
+    monkeypatch.chdir(tmp_path)
+    opt = options.default_options(modulation="qpsk", log=True)
+    # --- modulator: two flushes append
+    m = ofdm.ofdm_mod(opt, msgq_limit=4, pad_for_usrp=False)
+    pay = make_payloads(6, 300, seed=12)
+    for p in pay[:3]:
+        m.send_pkt(p)
+    a = m.flush()
+    for p in pay[3:]:
+        m.send_pkt(p)
+    b = m.flush()
+    logs = _read_logs(str(tmp_path))
+    assert all(n in logs for n in TX_LOGS)
+    cfg = make_cfg("qpsk")
+    cfg.tx_amplitude = 1.0                       # ofdm_mod on its own: transmit_path's amplitude block is not in it
+    N, CP = 512, 128
+    oa, ob = (orc.tx(cfg, part, want_taps=True, want_ifft=True) for part in (pay[:3], pay[3:]))     # (one batch per flush)
+    assert np.array_equal(a, oa[0]) and np.array_equal(b, ob[0])
+    freq_o, ifft_o = np.concatenate([oa[1], ob[1]]), np.concatenate([oa[3], ob[3]])
+    assert np.array_equal(logs["ofdm_preambles.dat"].reshape(-1, N), freq_o)
+    assert np.array_equal(logs["ofdm_ifft_c.dat"].reshape(-1, N), ifft_o)
+    assert np.array_equal(logs["ofdm_cp_adder_c.dat"].reshape(-1, N + CP)[:, CP:], ifft_o)
+    assert len(logs["ofdm_mapper_c.dat"]) == (len(freq_o) - len(pay)) * N          # every symbol but the preambles
+    # --- demodulator, one-shot calls: the second call appends to the first
+    cfgc, payc, iq = _capture(orc, npkt=40, seed=9)
+    d = ofdm.ofdm_demod(opt)
+    first = d.work(iq[:200000])
+    one = _read_logs(str(tmp_path))
+    assert all(n in one for n in RX_LOGS)
+    e = d.engine()
+    assert np.array_equal(one["ofdm_receiver-chan_filt_c.dat"], e.tap(_abi.TAP_RX_CHAN_FILT))
+    assert np.array_equal(one["ofdm_receiver-fft_out_c.dat"], e.tap(_abi.TAP_RX_FFT).reshape(-1))
+    assert np.array_equal(one["ofdm_frame_sink_c.dat"], e.tap(_abi.TAP_RX_SINK).reshape(-1), equal_nan=True)
+    d.work(iq[:200000])
+    two = _read_logs(str(tmp_path))
+    for n in RX_LOGS:
+        assert len(two[n]) == 2 * len(one[n]) and np.array_equal(two[n][:len(one[n])], one[n], equal_nan=True), n
+    # --- a fed stream: the files of the chunked run equal those of one call on the whole capture
+    os.makedirs("whole")
+    os.makedirs("chunked")
+    monkeypatch.chdir(tmp_path / "whole")
+    dw = ofdm.ofdm_demod(opt)
+    want = dw.work(iq)
+    whole = _read_logs(".")
+    monkeypatch.chdir(tmp_path / "chunked")
+    dc = ofdm.ofdm_demod(opt)
+    got = []
+    for k in range(0, len(iq), 150000):
+        got += dc.feed(iq[k:k + 150000])
+    got += dc.flush()
+    assert got == want
+    chunked = _read_logs(".")
+    for n in RX_LOGS:
+        assert len(chunked[n]) == len(whole[n]), n
+        assert np.array_equal(chunked[n], whole[n], equal_nan=True), n
