@@ -137,7 +137,19 @@ struct SlicerGrid {
   uint8_t idx[256];   // constellation index of (real level a, imaginary level b) at a * ni + b
 };
 
+// Frame counts known on the device only: the sampler's bookkeeping (k_frames) leaves the flags it rejects at either end
+// of the stream in two counters; kernels queued behind it without a host round trip take j0 / nframes from there
+// (lo == nullptr: the host's values are in force).
+struct DynFrames {
+  const unsigned int* lo;
+  const unsigned int* hi;
+  uint32_t npeaks;
+};
+__device__ __forceinline__ uint32_t dyn_nframes(const DynFrames& d, uint32_t stat) { return d.lo ? d.npeaks - *d.lo - *d.hi : stat; }
+__device__ __forceinline__ uint32_t dyn_j0(const DynFrames& d, uint32_t stat) { return d.lo ? *d.lo : stat; }
+
 struct DemodParams {
+  DynFrames dyn;
   int N, CP, L, occ, zl, nmap, nbits, arity, shift;
   float phase_gain, freq_gain, eq_gain;
   // Sign slicer for the two-level constellations (BPSK on the real axis, QPSK = a symmetric 2 x 2 grid): a point whose
@@ -383,6 +395,8 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
 
   const int t = threadIdx.x;
   const uint32_t f = blockIdx.x;
+  const uint32_t q_nframes = dyn_nframes(q.dyn, q.nframes), q_j0 = dyn_j0(q.dyn, q.j0);
+  if (f >= q_nframes) return;  // (grid sized by an upper bound when the count lives on the device)
   if (q.tap_mode && q.invalid[f]) return;
 
   // sink state (uniform across the block)
@@ -415,7 +429,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
 
   uint32_t cf = f;  // frame whose symbols are being consumed
   for (;;) {
-    const uint32_t j = q.j0 + cf;
+    const uint32_t j = q_j0 + cf;
     const uint64_t p = q.peaks[j];
     const uint32_t K = q.K[j];
     const uint64_t symb = q.sym_base[j];
@@ -730,10 +744,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
       }
     }
     if (done) break;
-    if (cf + 1 >= q.nframes) break;
+    if (cf + 1 >= q_nframes) break;
     cf++;  // the next preamble arrives while the sink is not searching: it is consumed as data
   }
-  if (!done) end_frame = q.nframes - 1;
+  if (!done) end_frame = q_nframes - 1;
 
   if (!q.tap_mode && t == 0) {
     FrameResult r;
@@ -748,9 +762,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
 // ------------------------------------------------------------------------------------
 // chain resolution: frames swallowed by an earlier, still unfinished packet are invalid
 // ------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_chain_collect(const FrameResult* __restrict__ res, uint32_t nframes,
+__global__ void __launch_bounds__(256) k_chain_collect(const FrameResult* __restrict__ res, uint32_t nframes_s, DynFrames dyn,
                                                         uint32_t* __restrict__ list, uint32_t cap, unsigned int* count) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nframes = dyn_nframes(dyn, nframes_s);
   if (f >= nframes) return;
   if (res[f].end_frame > f) {
     const unsigned int k = atomicAdd(count, 1u);
@@ -762,10 +777,11 @@ __global__ void __launch_bounds__(256) k_chain_collect(const FrameResult* __rest
 // `pre` (chunked streams): the first npre frames were settled by earlier calls -- pre[f] != 0 says frame f was
 // swallowed by a packet that began before it (possibly before this call's first sample): it is invalid and is
 // no chain head here either.
-__global__ void k_chain_resolve(const FrameResult* __restrict__ res, uint32_t nframes, uint32_t* __restrict__ list,
+__global__ void k_chain_resolve(const FrameResult* __restrict__ res, uint32_t nframes_s, DynFrames dyn, uint32_t* __restrict__ list,
                                 uint32_t cap, const unsigned int* __restrict__ count, uint8_t* __restrict__ invalid,
                                 unsigned int* overflow, const uint8_t* __restrict__ pre, uint32_t npre) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t nframes = dyn_nframes(dyn, nframes_s);
   for (uint32_t f = 0; f < npre && f < nframes; f++)
     if (pre[f]) invalid[f] = 1;
   unsigned int n = *count;
@@ -807,6 +823,7 @@ __global__ void k_chain_resolve(const FrameResult* __restrict__ res, uint32_t nf
 // unmake_packet
 // ------------------------------------------------------------------------------------
 struct DeframeParams {
+  DynFrames dyn;
   uint32_t nframes;
   const FrameResult* res;
   const uint8_t* invalid;
@@ -831,7 +848,10 @@ struct DeframeParams {
 
 __global__ void __launch_bounds__(256) k_deframe_count(DeframeParams q) {
   const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= q.nframes) return;
+  if (f >= dyn_nframes(q.dyn, q.nframes)) {
+    if (q.dyn.lo && f < q.dyn.npeaks) q.key[f] = 0;  // (the scan behind this kernel runs over the upper bound)
+    return;
+  }
   uint64_t key = 0;
   if (q.invalid[f]) {
     atomicAdd((unsigned long long*)&q.counters[3], 1ull);
@@ -857,7 +877,7 @@ __global__ void __launch_bounds__(256) k_deframe_write(DeframeParams q) {
   const int lane = lane_id(), w = wave_id();
   uint32_t* stage = stage_all[w];
   const uint32_t f = blockIdx.x * 4 + (uint32_t)w;
-  if (f >= q.nframes) return;
+  if (f >= dyn_nframes(q.dyn, q.nframes)) return;
   if (q.invalid[f]) return;
   const FrameResult r = q.res[f];
   if (r.status != FR_COMPLETE) return;
@@ -927,7 +947,7 @@ __global__ void __launch_bounds__(256) k_deframe_write(DeframeParams q) {
     q.out_off[ord] = boff;
     q.out_len[ord] = plen;
     q.out_ok[ord] = (uint8_t)ok;  // (packet / CRC totals are summed by the host from these flags)
-    q.out_pos[ord] = q.peaks[q.j0 + f];
+    q.out_pos[ord] = q.peaks[dyn_j0(q.dyn, q.j0) + f];
   }
 }
 
