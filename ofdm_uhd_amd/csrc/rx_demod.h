@@ -18,7 +18,7 @@
 #include "common.h"
 #include "fft.h"
 #ifndef DEMOD_PK
-#define DEMOD_PK false  // hand-packed butterflies (fft.h)
+#define DEMOD_PK true  // hand-packed butterflies (fft.h)
 #endif
 #include "host_util.h"
 

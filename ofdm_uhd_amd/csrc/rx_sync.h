@@ -145,25 +145,33 @@ __global__ void __launch_bounds__(256, FILTER_W) k_chan_filter(FilterParams p) {
   const int B = p.B, ntm1 = p.ntm1;
   FftTwRegs<F> twr;
   twr.load(p.twF, t);
-  c32 Hr[8], xn[8];
+  c32 Hr[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) Hr[m] = p.Hf[t + m * TF];
-  // first output sample of this thread's block in round r: (r * BPR + g) * B - goff
-  uint64_t r = blockIdx.x;
-  auto load_window = [&](uint64_t rr) {
+  // first output sample of this thread's block in round r: (r * BPR + g) * B - goff.  A round whose windows and outputs
+  // all lie inside the stream (every round but the first and the last few) needs no per-sample bounds test: one
+  // pointer per thread plus constant offsets.
+  auto interior = [&](uint64_t rr) -> bool {
+    const int64_t lo = (int64_t)(rr * BPR * (uint64_t)B) - p.goff - ntm1;
+    const int64_t hi = (int64_t)((rr * BPR + BPR - 1) * (uint64_t)B) - p.goff + B;  // one past the round's last output
+    return lo >= 0 && (uint64_t)hi <= p.nsamples;
+  };
+  auto load_window = [&](c32 (&xn)[8], uint64_t rr) {
     const int64_t x0 = (int64_t)((rr * BPR + (uint64_t)g) * (uint64_t)B) - p.goff - ntm1 + t;
+    if (interior(rr)) {  // (uniform)
+      const c32* px = p.x + x0;
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int64_t xi = x0 + m * TF;
-      xn[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
+      for (int m = 0; m < 8; m++) xn[m] = px[m * TF];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int64_t xi = x0 + m * TF;
+        xn[m] = (xi >= 0 && (uint64_t)xi < p.nsamples) ? p.x[xi] : mk(0.f, 0.f);
+      }
     }
   };
-  if (r < p.nrounds) load_window(r);
-  for (; r < p.nrounds; r += gridDim.x) {
-    c32 e[8];
-#pragma unroll
-    for (int m = 0; m < 8; m++) e[m] = xn[m];
-    if (r + gridDim.x < p.nrounds) load_window(r + gridDim.x);
+  // one round: window e -> transform -> x transformed taps -> inverse -> the last B points out
+  auto do_round = [&](c32 (&e)[8], uint64_t r) {
     // Opaque copy of the thread's place in its block, renewed every round: otherwise the compiler hoists the
     // LDS addresses of all passes out of the loop (~40 registers) and spills.
     int tt = t;
@@ -182,10 +190,30 @@ __global__ void __launch_bounds__(256, FILTER_W) k_chan_filter(FilterParams p) {
       fft_run1<F, true, FILTER_PK>(e, tt, sc, twr, FftBlockSync());
     }
     const int64_t bs = (int64_t)((r * BPR + (uint64_t)g) * (uint64_t)B) - p.goff;  // first output of the block
+    if (interior(r)) {  // (uniform)
+      c32* py = p.y + (bs + (t - ntm1));
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      const int64_t n = bs + (t + m * TF - ntm1);
-      if (t + m * TF >= ntm1 && n >= 0 && (uint64_t)n < p.nsamples) p.y[n] = e[m];
+      for (int m = 0; m < 8; m++)
+        if (t + m * TF >= ntm1) py[m * TF] = e[m];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int64_t n = bs + (t + m * TF - ntm1);
+        if (t + m * TF >= ntm1 && n >= 0 && (uint64_t)n < p.nsamples) p.y[n] = e[m];
+      }
+    }
+  };
+  // two windows take turns: while one is transformed the other one's loads are in flight (no register copy)
+  c32 xa[8], xb[8];
+  uint64_t r = blockIdx.x;
+  const uint64_t stride = gridDim.x;
+  if (r < p.nrounds) load_window(xa, r);
+  for (; r < p.nrounds; r += 2 * stride) {
+    if (r + stride < p.nrounds) load_window(xb, r + stride);
+    do_round(xa, r);
+    if (r + stride < p.nrounds) {
+      if (r + 2 * stride < p.nrounds) load_window(xa, r + 2 * stride);
+      do_round(xb, r + stride);
     }
   }
 }

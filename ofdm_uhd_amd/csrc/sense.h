@@ -34,10 +34,16 @@ struct SenseParams {
 
 constexpr int sense_threads(int ns) { return ns / 8 < 256 ? 256 : ns / 8; }
 constexpr int sense_groups(int ns) { return sense_threads(ns) / (ns / 8); }
-constexpr int sense_lds_bytes(int ns) { return sense_groups(ns) * fft_lds_bytes(ns); }
+// Long transforms (a workgroup of 256 / 512 threads per vector, NS >= 2048) read their twiddles from a table in LDS and
+// fetch the window taps anew every round: with both in registers the kernel needs 184 of them -- ONE workgroup per CU,
+// eight waves that spend their time at the transform's barriers (C5: 2.0 ms alone, 3.9 ms beside the demodulator).
+constexpr bool sense_lean(int ns) { return ns >= 2048; }
+constexpr int sense_lds_bytes(int ns) {
+  return sense_groups(ns) * fft_lds_bytes(ns) + (sense_lean(ns) ? fft_tw_lds_points(ns) * (int)sizeof(c32) : 0);
+}
 
 template <int NS>
-__global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
+__global__ void __launch_bounds__(sense_threads(NS), sense_lean(NS) ? 4 : 1) k_sense(SenseParams p) {
   constexpr int TPT = NS / 8;          // threads per transform
   constexpr int G = sense_groups(NS);  // transforms in flight per workgroup
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -48,6 +54,7 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
   const uint64_t period = (uint64_t)p.tune_delay + p.dwell_delay;
   const uint64_t v0 = msg * period + p.tune_delay;  // first accrued vector of this message
 
+  constexpr bool LEAN = sense_lean(NS);
   float w[8], mx[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) {
@@ -57,8 +64,14 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
   c32* my = lds + (size_t)g * fft_lds_bufs(NS) * fft_lds_points(NS);
   // a thread keeps its place in its transform for the whole dwell: its twiddles live in registers.  (Fetched per round
   // they would be global loads whose waits -- the vector-memory counter is in order -- also wait for the prefetch.)
-  FftTwRegs<NS> twr;
-  twr.load(p.tw, t);
+  FftTwRegs<LEAN ? 64 : NS> twr;
+  c32* twl = lds + (size_t)G * fft_lds_bufs(NS) * fft_lds_points(NS);  // (lean) the twiddle table
+  if constexpr (LEAN) {
+    for (int i = tid; i < fft_tw_used(NS); i += sense_threads(NS)) twl[lpad(i)] = p.tw[i];
+    __syncthreads();
+  } else {
+    twr.load(p.tw, t);
+  }
   const uint32_t stride = p.nsplit * G;
   // every group of the workgroup runs the same number of rounds (barriers inside fft_run)
   const uint32_t rounds = (p.dwell_delay + stride - 1) / stride;
@@ -84,7 +97,14 @@ __global__ void __launch_bounds__(sense_threads(NS)) k_sense(SenseParams p) {
 #pragma unroll
       for (int m = 0; m < 8; m++) nx[m] = ln ? src[t + m * TPT] : mk(0.f, 0.f);
     }
-    if constexpr (TPT <= WAVE) {
+    if constexpr (LEAN) {
+      int tt = t;  // opaque copy, renewed every round: keeps the passes' LDS addresses out of the registers
+      asm volatile("" : "+v"(tt));
+      fft_run_tw<NS, false, FftBlockSync, SENSE_PK, FftTwLds>(e, tt, my, FftTwLds{twl}, FftBlockSync());
+      // the window taps of the next round (L2): fetched behind the transform, where the registers are free again
+#pragma unroll
+      for (int m = 0; m < 8; m++) w[m] = p.win[tt + m * TPT];
+    } else if constexpr (TPT <= WAVE) {
       fft_run_tw<NS, false, FftWaveSync, SENSE_PK, FftTwRegs<NS>>(e, t, my, twr, FftWaveSync());
     } else {
       fft_run_tw<NS, false, FftBlockSync, SENSE_PK, FftTwRegs<NS>>(e, t, my, twr, FftBlockSync());

@@ -10,7 +10,7 @@
 #include "common.h"
 #include "fft.h"
 #ifndef TX_PK
-#define TX_PK false  // hand-packed butterflies (fft.h)
+#define TX_PK true  // hand-packed butterflies (fft.h)
 #endif
 
 struct TxParams {
