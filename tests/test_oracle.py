@@ -49,12 +49,16 @@ def test_rx_matches_numpy_model(orc, mod, N, occ, CP, plen, npkt, cfo):
     r = orc.rx(cfg, iq, ALL_TAPS)
     m = npm.rx(cfg, iq)
     assert np.abs(r.tap(_abi.TAP_RX_CHAN_FILT) - m["y"]).max() < 2e-6
-    # (an FFT filter's rounding error is relative to the largest sample of its block, not to the local level:
-    #  where the burst ends the window energy R is small and M = |P|^2/R^2 amplifies it to 1e-4 at 55 dB SNR; the flag positions below are the sharp check)
-    assert np.abs(r.tap(_abi.TAP_RX_METRIC) - m["u"]).max() < 2e-4
+    # metric: 1e-5 of (1 + M-bar).  Where a burst ends the window energy R collapses and M = |P|^2 / R^2 -- and with it
+    # M-bar, up to ~30 -- amplifies the FFT filter's rounding (relative to the largest sample of its block): the bound
+    # scales with M-bar there and stays at 1e-5 everywhere else (no global loosening)
+    uo, un = r.tap(_abi.TAP_RX_METRIC).astype(np.float64), m["u"]
+    assert np.all(np.abs(uo - un) <= 1e-5 * (1.0 + (un + 1.0)))
     assert list(r.tap(_abi.TAP_RX_PEAKS)) == list(m["peaks"])
-    # (false triggers where the burst ends take the angle of a small, ill-conditioned P: same remark as above)
-    assert np.abs(r.tap(_abi.TAP_RX_ANGLES) - m["angles"]).max() < 1e-4
+    # angles: 5e-7 at the packets' flags; the false trigger where the burst ends takes the angle of a small,
+    # ill-conditioned P (same remark as above): 1e-5
+    da = np.abs(r.tap(_abi.TAP_RX_ANGLES) - m["angles"])
+    assert da.max() < 1e-5 and np.sort(da)[:-1].max() < 2e-6
     # closed-form sampler (np_model.sampler_frames) == the automaton the oracle runs
     assert [tuple(x) for x in r.tap(_abi.TAP_RX_FRAMES)] == [tuple(x) for x in m["frames"]]
     F = r.tap(_abi.TAP_RX_FFT)
@@ -161,17 +165,16 @@ def test_sampler_timeout_path(orc):
     b = orc.tx(cfg, pay[1:], lead=0, tail=(N + CP) + 2 * N)
     iq = np.concatenate([a, gap, b])
     sigma = float(np.sqrt(np.mean(np.abs(a[2 * N:]) ** 2) / 1000.0))
-    clean = 0
-    for seed in range(6):     # the closed form must hold for every noise realisation; the scenario (time-out fired,
-        x = iq.copy()         # both packets back) is luck-dependent at N = 64 and must come up at least once
+    for seed in range(6):     # the closed form must hold for every noise realisation, and the time-out must fire in each
+        x = iq.copy()
         orc.channel(x, sigma=sigma, seed=seed)
         r = orc.rx(cfg, x, 1 << _abi.TAP_RX_METRIC)
         peaks = r.tap(_abi.TAP_RX_PEAKS)
         frames = npm.sampler_frames(peaks, len(x), N, CP, cfg.sampler_timeout)
         assert [tuple(f) for f in r.tap(_abi.TAP_RX_FRAMES)] == frames
-        if max(k for _, k in frames) == cfg.sampler_timeout + 1 and [p for ok, p in r.packets if ok] == pay:
-            clean += 1
-    assert clean >= 1
+        assert max(k for _, k in frames) == cfg.sampler_timeout + 1
+        if seed == 0:         # (this realisation also brings both packets back: N = 64 at 30 dB loses one in the others)
+            assert [p for ok, p in r.packets if ok] == pay
 
 
 def test_pad_symbols_are_counter_based(orc):
