@@ -205,12 +205,29 @@ __host__ __device__ inline int demod_hinv_len(int n, int occ, int shift) {
 __host__ __device__ inline int demod_red_floats(int n) { return n / 8 == WAVE ? 0 : 64; }
 // The sink's carrier map is read once per carrier and symbol: in LDS too, unless that costs a workgroup per CU
 // (DemodParams::smap_lds, the host decides).
+// A one-wave frame (N = 512) shares its workgroup with DEMOD_FPW - 1 others: the tables every frame reads (twiddles,
+// constellation, slicer grid, carrier map: 4.4 KB at C2) are staged once per workgroup, which brings the LDS a frame
+// costs from 12.4 to 9.1 KB -- sixteen frames per CU instead of twelve.  The frames of a workgroup never meet at a
+// barrier after the staging (each is a wave of its own: wave-level fences only).
+#ifndef DEMOD_FPW
+#define DEMOD_FPW 4
+#endif
+__host__ __device__ constexpr int demod_fpw(int n) { return n / 8 == WAVE ? DEMOD_FPW : 1; }
+// tables shared by the frames of a workgroup
+__host__ __device__ inline int demod_lds_shared(int n, bool twl, bool smap_lds, int arity, int nmap, bool grid) {
+  const int b = (twl ? fft_tw_lds_points(n) : 0) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
+                (grid ? (int)sizeof(SlicerGrid) : 0) + (smap_lds ? ((nmap * 2 + 3) & ~3) : 0);
+  return (b + 15) & ~15;
+}
+// one frame's own: transform buffer | hinv | dfe | reduction scratch | the bits of one symbol
+__host__ __device__ inline int demod_lds_frame(int n, int occ, int nmap, int nbits, int shift) {
+  const int b = fft_lds_points(n) * (int)sizeof(c32) + (demod_hinv_len(n, occ, shift) + occ) * (int)sizeof(c32) +
+                demod_red_floats(n) * (int)sizeof(float) + ((demod_symbits_words(nmap, nbits) + 3) & ~3) * 4;
+  return (b + 15) & ~15;
+}
 __host__ __device__ inline int demod_lds_bytes(int n, bool twl, bool smap_lds, int occ, int arity, int nmap, int nbits, int shift,
                                                bool grid) {
-  return (fft_lds_points(n) + (twl ? fft_tw_lds_points(n) : 0)) * (int)sizeof(c32) +
-         (demod_hinv_len(n, occ, shift) + occ) * (int)sizeof(c32) + arity * (int)sizeof(c32) +
-         demod_red_floats(n) * (int)sizeof(float) + ((demod_symbits_words(nmap, nbits) + 3) & ~3) * 4 +
-         (grid ? (int)sizeof(SlicerGrid) : 0) + (smap_lds ? ((nmap * 2 + 3) & ~3) : 0);
+  return demod_lds_shared(n, twl, smap_lds, arity, nmap, grid) + demod_fpw(n) * demod_lds_frame(n, occ, nmap, nbits, shift);
 }
 
 // Two wave-wide sums in the normative order (oracle: lane_tree_sum -- partner = lane ^ d for d = 32, 16, ... 1, each
@@ -359,7 +376,7 @@ __device__ __noinline__ dc dexpj(double ph) {
 }
 
 #ifndef DEMOD_WAVES
-#define DEMOD_WAVES 3  // waves per SIMD the register allocation aims at (measured best of 2 / 3 / 4)
+#define DEMOD_WAVES 4  // waves per SIMD the register allocation aims at (114 registers since the preamble phasors left the symbol loop)
 #endif
 // Frames of four waves and more (N >= 2048) get the 128-register budget: one more workgroup per CU, spills and all
 // (C5: 3.9 -> 2.95 ms with two workgroups instead of one; C3: 2.30 -> 2.05 ms with four instead of three) -- the LDS
@@ -369,37 +386,68 @@ __device__ __noinline__ dc dexpj(double ph) {
 #define DEMOD_WAVES_BIG 4
 #endif
 __host__ __device__ constexpr int demod_waves_per_simd(int n) { return (n / 8 >= 256) ? DEMOD_WAVES_BIG : DEMOD_WAVES; }
+// synchronisation of one frame's threads: a workgroup barrier -- or, where the frame is one wave sharing its workgroup
+// with other frames, wave-level fences (DS instructions of a wave execute in order)
+template <int FPW>
+__device__ __forceinline__ void frame_sync() {
+  if constexpr (FPW > 1) {
+    FftWaveSync()();
+  } else {
+    __syncthreads();
+  }
+}
 template <int N, bool TWL>
-__global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_simd(N)) k_rx_demod(DemodParams q) {
+__global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), demod_waves_per_simd(N)) k_rx_demod(DemodParams q) {
   static_assert(TWL || fft_onebuf(N), "up to N = 1024 the twiddles are always in LDS");
   constexpr int T = N / 8;
+  constexpr int FPW = demod_fpw(N);
   extern __shared__ __align__(16) unsigned char smem[];
-  c32* fftbuf = reinterpret_cast<c32*>(smem);
-  c32* Ysh = fftbuf;  // the first FFT buffer is free again after the last pass: shifted spectrum, linear
-  c32* twl = fftbuf + fft_lds_points(N);  // the twiddle table (N <= 1024)
-  c32* hinv = twl + (TWL ? fft_tw_lds_points(N) : 0);
-  // correlator scratch (occ + 2*shift + 1 floats): the equaliser's own array -- it is rebuilt from scratch right after
-  // the correlation (block barriers between)
-  float* sd = reinterpret_cast<float*>(hinv);
-  c32* dfe = hinv + demod_hinv_len(N, q.occ, q.shift);
-  c32* cst = dfe + q.occ;
-  float* red = reinterpret_cast<float*>(cst + q.arity);
-  uint32_t* sbits = reinterpret_cast<uint32_t*>(red + demod_red_floats(N));
-  const int sbw = demod_symbits_words(q.nmap, q.nbits);
-  SlicerGrid* grid = reinterpret_cast<SlicerGrid*>(sbits + ((sbw + 3) & ~3));
+  const bool use_grid = q.grid != nullptr;
+  // ---- tables shared by the workgroup's frames: twiddles | constellation | slicer grid | carrier map ----
+  c32* twl = reinterpret_cast<c32*>(smem);  // the twiddle table (N <= 1024, longer transforms when it costs no workgroup)
+  c32* cst = twl + (TWL ? fft_tw_lds_points(N) : 0);
+  SlicerGrid* grid = reinterpret_cast<SlicerGrid*>(cst + q.arity);
   // the sink's carrier map, read once per carrier and symbol: in LDS, so that the symbol loop's only global loads
   // are the next symbol's samples (a wave's vector-memory counter is in order: any other load's wait would wait for
   // the prefetch too)
   int16_t* smapL = reinterpret_cast<int16_t*>(reinterpret_cast<unsigned char*>(grid) + (q.grid ? sizeof(SlicerGrid) : 0));
-  const bool use_grid = q.grid != nullptr;
+  // ---- this frame's own ----
+  // (a frame's threads fill one wave: the slot is wave-uniform -- say so, and its LDS base lives in a scalar register)
+  const int slot = FPW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T)) : 0;
+  unsigned char* mine = smem + demod_lds_shared(N, TWL, q.smap_lds != 0, q.arity, q.nmap, use_grid) +
+                        slot * demod_lds_frame(N, q.occ, q.nmap, q.nbits, q.shift);
+  c32* fftbuf = reinterpret_cast<c32*>(mine);
+  c32* Ysh = fftbuf;  // the FFT buffer is free again after the last pass: shifted spectrum, linear
+  c32* hinv = fftbuf + fft_lds_points(N);
+  // correlator scratch (occ + 2*shift + 1 floats): the equaliser's own array -- it is rebuilt from scratch right after
+  // the correlation (barriers between)
+  float* sd = reinterpret_cast<float*>(hinv);
+  c32* dfe = hinv + demod_hinv_len(N, q.occ, q.shift);
+  float* red = reinterpret_cast<float*>(dfe + q.occ);
+  uint32_t* sbits = reinterpret_cast<uint32_t*>(red + demod_red_floats(N));
+  const int sbw = demod_symbits_words(q.nmap, q.nbits);
 
-  const int t = threadIdx.x;
-  const uint32_t f = blockIdx.x;
+  const int t = FPW > 1 ? (int)(threadIdx.x % T) : (int)threadIdx.x;
+  const uint32_t f = blockIdx.x * FPW + (uint32_t)slot;
   const uint32_t q_nframes = dyn_nframes(q.dyn, q.nframes), q_j0 = dyn_j0(q.dyn, q.j0);
-  if (f >= q_nframes) return;  // (grid sized by an upper bound when the count lives on the device)
+
+  // the shared tables, staged by the whole workgroup; the one barrier every frame of it takes part in
+  {
+    const int nthr = FPW * T, th = threadIdx.x;  // (= blockDim.x)
+    for (int i = th; i < q.arity; i += nthr) cst[i] = q.constellation[i];
+    if constexpr (TWL)
+      for (int i = th; i < fft_tw_used(N); i += nthr) twl[lpad(i)] = q.tw[i];
+    if (q.smap_lds)
+      for (int i = th; i < q.nmap; i += nthr) smapL[i] = q.smap[i];
+    if (use_grid)
+      for (int i = th; i < (int)(sizeof(SlicerGrid) / 4); i += nthr)
+        reinterpret_cast<uint32_t*>(grid)[i] = reinterpret_cast<const uint32_t*>(q.grid)[i];
+  }
+  __syncthreads();
+  if (f >= q_nframes) return;  // (grid sized by an upper bound when the count lives on the device; a workgroup's last slots)
   if (q.tap_mode && q.invalid[f]) return;
 
-  // sink state (uniform across the block)
+  // sink state (uniform across the frame's threads)
   int sstate = 0;  // 0 search, 1 have_sync, 2 have_header
   float pll_phase = 0.f, pll_freq = 0.f;
   uint32_t nbits_total = 0;  // bits demapped since enter_have_sync
@@ -417,15 +465,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
     hinv[i] = mk(0.f, 0.f);
     dfe[i] = mk(1.f, 0.f);
   }
-  for (int i = t; i < q.arity; i += T) cst[i] = q.constellation[i];
-  if constexpr (TWL)
-    for (int i = t; i < fft_tw_used(N); i += T) twl[lpad(i)] = q.tw[i];
-  if (q.smap_lds)
-    for (int i = t; i < q.nmap; i += T) smapL[i] = q.smap[i];
-  if (use_grid)
-    for (int i = t; i < (int)(sizeof(SlicerGrid) / 4); i += T)
-      reinterpret_cast<uint32_t*>(grid)[i] = reinterpret_cast<const uint32_t*>(q.grid)[i];
-  __syncthreads();
+  frame_sync<FPW>();
 
   uint32_t cf = f;  // frame whose symbols are being consumed
   for (;;) {
@@ -443,19 +483,9 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
     // (the two step phasors are the same in every lane: held in scalar registers, eight vector registers fewer)
     const dc RL = dc_uniform(dexpj(st * (double)q.L));
     const dc RT = dc_uniform(dexpj(st * (double)T));
-    // the preamble symbol ends ON the flag: its samples before p belong to the previous segment(s)
+    // the preamble symbol ends ON the flag: its samples before p belong to the previous segment(s).  (Its phasors are
+    // formed inside the k == 0 branch below: they are needed once per frame, not as registers held over the symbol loop.)
     const bool pre_simple = (j == 0) || (q.peaks[j - 1] <= s00);
-    dc Ap = {1.0, 0.0}, RTp = {1.0, 0.0};
-    const dc Rflag = dexpj(q.Phi[j] + st);  // the flagged sample itself already runs on the new frequency
-    if (pre_simple && j > 0) {
-      const double stq = q.step[j - 1];
-      Ap = dexpj(q.Phi[j - 1] + stq * (double)((int64_t)(s00 + (uint64_t)t) - (int64_t)q.peaks[j - 1] + 1));
-      RTp = dexpj(stq * (double)T);
-    } else if (pre_simple && q.ref_on) {
-      // chunked streams: what precedes this call's first flag runs on the NCO line carried in
-      Ap = dexpj(q.ref_phi + q.ref_step * (double)((int64_t)(s00 + (uint64_t)t) - q.ref_peak + 1));
-      RTp = dexpj(q.ref_step * (double)T);
-    }
 
     // prefetch of the next symbol's samples
     c32 nx[8];
@@ -482,6 +512,17 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
           r = dmul(r, RT);
         }
       } else if (pre_simple) {
+        dc Ap = {1.0, 0.0}, RTp = {1.0, 0.0};
+        const dc Rflag = dexpj(q.Phi[j] + st);  // the flagged sample itself already runs on the new frequency
+        if (j > 0) {
+          const double stq = q.step[j - 1];
+          Ap = dexpj(q.Phi[j - 1] + stq * (double)((int64_t)(s00 + (uint64_t)tl) - (int64_t)q.peaks[j - 1] + 1));
+          RTp = dexpj(stq * (double)T);
+        } else if (q.ref_on) {
+          // chunked streams: what precedes this call's first flag runs on the NCO line carried in
+          Ap = dexpj(q.ref_phi + q.ref_step * (double)((int64_t)(s00 + (uint64_t)tl) - q.ref_peak + 1));
+          RTp = dexpj(q.ref_step * (double)T);
+        }
         dc r = Ap;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
@@ -512,7 +553,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
       }
       // ---- fft_vcc(N, True, [1]*N, True): forward DFT, DC to the middle -------------------
       if constexpr (!fft_onebuf(N)) {
-        fft_run1<N, false, DEMOD_PK, FftBlockSync, FftTwLds>(e, tl, fftbuf, FftTwLds{twl}, FftBlockSync());
+        if constexpr (FPW > 1)
+          fft_run1<N, false, DEMOD_PK, FftWaveSync, FftTwLds>(e, tl, fftbuf, FftTwLds{twl}, FftWaveSync());
+        else
+          fft_run1<N, false, DEMOD_PK, FftBlockSync, FftTwLds>(e, tl, fftbuf, FftTwLds{twl}, FftBlockSync());
       } else if constexpr (TWL) {
         fft_run_tw<N, false, FftBlockSync, DEMOD_PK, FftTwLds>(e, tl, fftbuf, FftTwLds{twl}, FftBlockSync());
       } else {
@@ -525,10 +569,10 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
 #pragma unroll
         for (int m = 0; m < 8; m++) nx[m] = q.y[s1 + (uint64_t)(tl + m * T)];
       }
-      __syncthreads();  // every thread is done reading the FFT buffers before Ysh (= buffer A) is overwritten
+      frame_sync<FPW>();  // every thread is done reading the FFT buffers before Ysh (= buffer A) is overwritten
 #pragma unroll
       for (int m = 0; m < 8; m++) Ysh[(tl + m * T + N / 2) & (N - 1)] = e[m];
-      __syncthreads();
+      frame_sync<FPW>();
       if (q.tap_fft) {
 #pragma unroll
         for (int m = 0; m < 8; m++) q.tap_fft[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = Ysh[tl + m * T];
@@ -546,7 +590,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
           if (i >= 0 && i < N - 2) v = cnorm(csub(Ysh[i], Ysh[i + 2]));
           sd[r] = v;
         }
-        __syncthreads();
+        frame_sync<FPW>();
         int index = 0;
         float mx = 0.f;
         for (int i0 = q.zl - q.shift; i0 < q.zl + q.shift; i0 += 2) {
@@ -579,16 +623,16 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
             const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
             hinv[i] = cdiv(q.ks[i], cmul(comp, Y));
           }
-          __syncthreads();
+          frame_sync<FPW>();
           for (int i = 2 * t + 1; i < q.occ; i += 2 * T) {
             if (i + 1 < q.occ) {
               const c32 a1 = hinv[i + 1], a0 = hinv[i - 1];
               hinv[i] = mk((a1.re + a0.re) / 2.0f, (a1.im + a0.im) / 2.0f);
             }
           }
-          __syncthreads();
+          frame_sync<FPW>();
           if (t == 0 && !(q.occ & 1)) hinv[q.occ - 1] = hinv[q.occ - 2];
-          __syncthreads();
+          frame_sync<FPW>();
         }
       }
       c32 comp;
@@ -700,7 +744,7 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
       if (pll_phase < 0.0f) pll_phase += 6.28318530717958647692f;
       pll_phase = f32_uniform(pll_phase);
       pll_freq = f32_uniform(pll_freq);
-      __syncthreads();  // sbits complete for this symbol
+      frame_sync<FPW>();  // sbits complete for this symbol
       // ---- bytes of this symbol: header parse, message bytes to the raw slot -----------------------
       const uint32_t byte0 = nbits_total >> 3;                           // index of the byte at sbits bit 0
       nbits_total += (uint32_t)q.nmap * (uint32_t)q.nbits;
@@ -734,13 +778,13 @@ __global__ void __launch_bounds__((N / 8 < 64) ? 64 : N / 8, demod_waves_per_sim
           end_frame = cf;
         }
       }
-      __syncthreads();
+      frame_sync<FPW>();
       // carry the unfinished byte into the next symbol's buffer, clear the rest
       {
         const uint32_t keep = (nbits_total & 7u) ? sb8[nnew] : 0u;
-        __syncthreads();
+        frame_sync<FPW>();
         for (int i = t; i < sbw; i += T) sbits[i] = (i == 0) ? keep : 0u;
-        __syncthreads();
+        frame_sync<FPW>();
       }
     }
     if (done) break;
