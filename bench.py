@@ -152,6 +152,9 @@ def main():
                     help="receiver front end: 'pn' = the reference's Schmidl-Cox chain (default, the headline number); "
                          "'fixed' = its known-timing test mode (ofdm_receiver.py~:108-119): no filter, no metric -- "
                          "times the rest of the receiver on its own")
+    ap.add_argument("--iq-buffers", type=int, default=1, choices=(1, 2),
+                    help="2: steps alternate two IQ buffers, so that step i+1's modulator may run beside step i's channel "
+                         "filter (the engine orders a transmit batch only behind reads of the buffer it writes)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="BASELINE.json config to run (default c2 = configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
@@ -207,7 +210,7 @@ def main():
     lens = np.full(P, size, np.uint32)
     nsym, nsamp = eng.tx_frame_count(lens)
     d_blob = torch.from_numpy(blob).to(dev)                       # resident before the timed region
-    d_iq = torch.empty(nsamp * 2, dtype=torch.float32, device=dev)
+    d_iqs = [torch.empty(nsamp * 2, dtype=torch.float32, device=dev) for _ in range(args.iq_buffers)]
     d_out = torch.empty(P * size + 4096, dtype=torch.uint8, device=dev)
     max_pkts = P + 1024
 
@@ -231,7 +234,7 @@ def main():
     pipelined = not sense_on and args.sync == "pn" and not args.no_pipeline
 
     def tx(i):
-        n = eng.tx_device(d_blob.data_ptr(), offs, lens, d_iq.data_ptr(), nsamp, wait=False)
+        n = eng.tx_device(d_blob.data_ptr(), offs, lens, d_iqs[i % len(d_iqs)].data_ptr(), nsamp, wait=False)
         return n, dict(eng.last_stats)
 
     def run_steps(nsteps, tot, pipelined=pipelined):
@@ -240,6 +243,7 @@ def main():
             return npk, off, ln, ok
         n, tx_stats = tx(0)
         for i in range(nsteps):
+            d_iq = d_iqs[i % len(d_iqs)]
             if pipelined:
                 eng.rx_submit_device(d_iq.data_ptr(), n)
                 nxt = tx(i + 1) if i + 1 < nsteps else None
@@ -364,7 +368,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfgd["name"] + ("" if args.sync == "pn" else " -- SYNC='fixed' test mode (no filter / metric)"),
                        "packets_per_stream_per_step": P, "payload_bytes": size, "symbols_per_packet": nsym // P,
-                       "snr_db": args.snr, "streams": world, "parallelism": "independent streams, 1 per GPU",
+                       "snr_db": args.snr, "streams": world, "iq_buffers": args.iq_buffers, "parallelism": "independent streams, 1 per GPU",
                        "pipelining": ("TX of step i+1 queued on the handle's transmit stream behind the input stage of "
                                       "step i's RX" if pipelined else "none (the fused sensor reads the buffer to the end of RX)")},
             "crc_pass_rate": g["crc_ok"] / float(max(world * P * args.steps, 1)),

@@ -63,6 +63,12 @@ struct ofdm_handle {
   hipStream_t own_txs = nullptr, txs = nullptr;
   hipEvent_t ev_tx_done = nullptr, ev_rx_in = nullptr, ev_tx_staged = nullptr;
   bool tx_pending = false, rx_in_pending = false, tx_staged_pending = false;
+  // The receiver's reads of its input, newest and one before (a caller that alternates two IQ buffers lets batch
+  // i+1 be modulated into one while batch i is still filtered out of the other): a transmit batch waits for those
+  // whose buffer its output overlaps.  [0] is ev_rx_in itself.
+  hipEvent_t ev_rx_in_old = nullptr;
+  bool rx_in_old_pending = false;
+  uintptr_t rx_in_lo[2] = {0, 0}, rx_in_hi[2] = {0, 0};
   std::string err;
 
   // constant tables
@@ -295,6 +301,7 @@ static int create_impl(const ofdm_cfg* cfg, ofdm_handle* h) {
   h->txs = h->own_txs;
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_tx_done, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx_in, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_rx_in_old, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_tx_staged, hipEventDisableTiming));
 
   h->cfg.carrier_map[OFDM_MAX_CARRIER_HEX + 7] = 0;
@@ -513,6 +520,7 @@ extern "C" void ofdm_destroy(ofdm_handle* h) {
   h->prof.destroy();
   if (h->ev_tx_done) (void)hipEventDestroy(h->ev_tx_done);
   if (h->ev_rx_in) (void)hipEventDestroy(h->ev_rx_in);
+  if (h->ev_rx_in_old) (void)hipEventDestroy(h->ev_rx_in_old);
   if (h->ev_tx_staged) (void)hipEventDestroy(h->ev_tx_staged);
   if (h->own_txs) (void)hipStreamDestroy(h->own_txs);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -762,7 +770,14 @@ static int tx_enqueue(ofdm_handle* h, const uint8_t* payloads, const uint64_t* p
       FAIL(h, OFDM_E_INVAL, "ofdm_tx into the buffer of a submitted ofdm_rx that reads it to the end of the call (SYNC fixed / fused sensing): call ofdm_rx first");
   }
   // the receiver may still be reading the buffer this batch writes (ofdm_rx_submit / ofdm_rx in flight)
-  if (h->rx_in_pending && h->txs != h->stream) HIPCHK(h, hipStreamWaitEvent(h->txs, h->ev_rx_in, 0));
+  if (h->txs != h->stream) {
+    const uintptr_t o0 = (uintptr_t)iq_out, o1 = o0 + total * sizeof(c32);
+    // (host-pointer mode stages through the handle's own buffers: always ordered)
+    const bool all = !h->dev_ptrs;
+    if (h->rx_in_pending && (all || (o0 < h->rx_in_hi[0] && h->rx_in_lo[0] < o1))) HIPCHK(h, hipStreamWaitEvent(h->txs, h->ev_rx_in, 0));
+    if (h->rx_in_old_pending && (all || (o0 < h->rx_in_hi[1] && h->rx_in_lo[1] < o1)))
+      HIPCHK(h, hipStreamWaitEvent(h->txs, h->ev_rx_in_old, 0));
+  }
 
   c32* d_out = reinterpret_cast<c32*>(iq_out);
   if (!h->dev_ptrs) {

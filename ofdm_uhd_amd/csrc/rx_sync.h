@@ -36,6 +36,9 @@
 #define SYNC_GUARD 1.0e-3f                  // guard band of the float32 pre-selection
 #define SYNC_ILL 0.015625f                  // window energy below 1/64 of its running maximum: float32 has lost it
 #define SYNC_CHUNK_C 4096                   // candidates per allocation chunk (>= SYNC_TILE)
+#ifndef SYNC_MAX_WG
+#define SYNC_MAX_WG 5                        // most k_sync workgroups per CU the register budgets are built for
+#endif
 #define SYNC_CHUNK_P 1024                   // pieces per allocation chunk (>= SYNC_TILE / 2)
 
 struct SyncPiece {
@@ -219,19 +222,30 @@ __global__ void __launch_bounds__(256, FILTER_W) k_chan_filter(FilterParams p) {
 }
 
 struct SyncLds {
-  size_t ys, mt, mh, misc, total;
+  size_t ys, mt, mh, mh1, misc, total;
 };
 // LDS of k_sync: the ring of filtered samples | the tile's M values (mt) | the CP newest M values of the previous
-// tile (mh) | scan / vote scratch.
+// tile (mh), double-buffered: the next tile's are written while this tile's are still read | scan / vote scratch.
+// Where the history in front of a tile is short (fixed layout, H = R - T <= 1000 samples: N <= 512), mt OVERLAYS the
+// tile's own samples: every read of them precedes the barrier behind which M is written, the part the slide to the
+// front still reads lies behind mt's end, and the next tile's samples arrive only after mt's last read -- 9 KB less per
+// workgroup, which is what lets a CU hold five or six of them.
+__host__ __device__ inline bool sync_mt_overlay(int R) { return R - SYNC_TILE <= 1000 && R - SYNC_TILE <= SYNC_TILE; }
 __host__ __device__ inline SyncLds sync_lds_layout(int R, int HM) {
   SyncLds l;
   size_t o = 0;
   l.ys = o;
   o += (size_t)(sync_lp(R) + 2) * sizeof(c32);
   o = (o + 15) & ~(size_t)15;
-  l.mt = o;
-  o += ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  if (sync_mt_overlay(R)) {
+    l.mt = l.ys + (size_t)sync_lp(R - SYNC_TILE) * sizeof(c32);  // the tile's first sample (a multiple of 8: 16-aligned)
+  } else {
+    l.mt = o;
+    o += ((size_t)(sync_lp(SYNC_TILE) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  }
   l.mh = o;  // M history: the CP values before the tile
+  o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
+  l.mh1 = o;
   o += ((size_t)(sync_lp(HM) + 2) * sizeof(float) + 15) & ~(size_t)15;
   l.misc = o;
   o += 384;
@@ -723,7 +737,7 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p, FilterPa
   const FrontLds L1 = front_lds_layout(R, p.HM, FUSED ? fp.B : 8, FUSED ? F : 64);
   c32* ys = reinterpret_cast<c32*>(smem + (FUSED ? L1.ys : L0.ys));
   float* mh = reinterpret_cast<float*>(smem + (FUSED ? L1.mh0 : L0.mh));
-  float* mh_nxt = reinterpret_cast<float*>(smem + (FUSED ? L1.mh1 : L0.mh));  // (fused: the next tile's M history)
+  float* mh_nxt = reinterpret_cast<float*>(smem + (FUSED ? L1.mh1 : L0.mh1));  // the next tile's M history
   float* mt = reinterpret_cast<float*>(smem + (FUSED ? L1.mt : L0.mt));
   unsigned char* misc = smem + (FUSED ? L1.misc : L0.misc);
   float* scA = reinterpret_cast<float*>(misc);                 // 24 floats
@@ -909,7 +923,9 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p, FilterPa
       }
     }
     have_pre = false;
-    if (tile + 1 < tile_own1 && y_al16 && t0 + 2ull * T <= p.nsamples) {
+    // (five and more workgroups per CU hide the tile's load latency among themselves: no register prefetch there --
+    //  its sixteen registers are what that budget lacks)
+    if (W <= 4 && tile + 1 < tile_own1 && y_al16 && t0 + 2ull * T <= p.nsamples) {
       const float4* src = reinterpret_cast<const float4*>(p.y + t0 + T);
 #pragma unroll
       for (int r = 0; r < SYNC_V / 2; r++) ypre[r] = src[tl + r * SYNC_THREADS];
@@ -1023,22 +1039,16 @@ __global__ void __launch_bounds__(SYNC_THREADS, W) k_sync(SyncParams p, FilterPa
     }
     float manc = 0.f;
     for (int m = -CP + tl; m < 0; m += SYNC_THREADS) manc += mh[sync_lp(HM + m)];
-    if constexpr (FUSED) {
-      // the CP newest M values become the next tile's history -- into the OTHER history buffer, before B5: behind it mt is
-      // the transforms' scratch again (the next tile's filter phase)
-      for (int i = tl; i < HM; i += SYNC_THREADS) mh_nxt[sync_lp(i)] = mt[sync_lp(T - HM + i)];
-    }
+    // the CP newest M values become the next tile's history -- into the OTHER history buffer, before B5: behind it mt
+    // belongs to the next tile's samples (or, fused, to the transforms' scratch) again
+    for (int i = tl; i < HM; i += SYNC_THREADS) mh_nxt[sync_lp(i)] = mt[sync_lp(T - HM + i)];
     float mex, mach;
     block_scan1_sum1(msum, manc, scB, &mex, &mach);  // B5
     STAMP(6);
-    if constexpr (FUSED) {
+    {
       float* sw_ = mh;
       mh = mh_nxt;
       mh_nxt = sw_;
-    } else {
-      // the CP newest M values become the next tile's history (every thread has done its reads of mh
-      // and mt before B5; mt is free from here on)
-      for (int i = tl; i < HM; i += SYNC_THREADS) mh[sync_lp(i)] = mt[sync_lp(T - HM + i)];
     }
     // Float32 has lost the window energy where it fell below SYNC_ILL of the largest value the running sums went
     // through since the tile's anchor: such a tile goes to the fixed-point evaluation whole (sync_finish_tile).
