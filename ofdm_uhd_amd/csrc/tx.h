@@ -231,8 +231,11 @@ struct TxGeom {
   }
 };
 
+#ifndef TX_WAVES
+#define TX_WAVES 1  // minimum waves per SIMD the register allocation must admit (1: no constraint)
+#endif
 template <int N>
-__global__ void __launch_bounds__(TxGeom<N>::WG)
+__global__ void __launch_bounds__(TxGeom<N>::WG, TX_WAVES)
     k_tx_mod(TxParams p, const uint8_t* __restrict__ framed, const uint64_t* __restrict__ framed_off,
              const uint64_t* __restrict__ sym_off, const uint32_t* __restrict__ sym_pkt, uint32_t uniform_spp,
              uint64_t nsym, uint64_t lead, c32* __restrict__ out, c32* __restrict__ freq_tap,
