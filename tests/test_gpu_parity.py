@@ -333,3 +333,24 @@ def test_channel_parity(orc):
     n = a[:100] - x[:100] * np.exp(1j * 0.002 * (5 + np.arange(100)))
     assert 0.005 < np.std(n.real) < 0.0095 and abs(np.mean(n)) < 0.004
     eng.close()
+
+
+FRONT_CASES = [c for c in CASES if c[1] <= 512]   # (the fused kernel needs wave-sized filter transforms: F <= 512)
+
+
+@pytest.mark.parametrize("mod,N,occ,CP,plen,npkt,snr,cfo", FRONT_CASES)
+def test_fused_front_end_parity(orc, monkeypatch, mod, N, occ, CP, plen, npkt, snr, cfo):
+    """The opt-in fused front end (OFDM_FRONT=1: the channel filter's blocks transformed inside k_sync, y written once
+    and never read back by the metric -- DESIGN.md section 5) against the oracle: every tap array_equal, and it is
+    really the fused kernel that ran (its profiling slot has a launch, the two-kernel slots have none)."""
+    monkeypatch.setenv("OFDM_FRONT", "1")
+    cfg = make_cfg(mod, N, occ, CP)
+    eng = _engine(cfg)
+    pay = make_payloads(npkt, plen)
+    x = loopback_stream(orc, cfg, pay, snr_db=snr, cfo_bins=cfo)
+    eng.prof_enable(True)
+    eng.prof_reset()
+    _check_rx(orc, cfg, eng, x)
+    prof = eng.prof()
+    assert prof["k_front"][1] >= 1 and prof["k_chan_filter"][1] == 0 and prof["k_sync"][1] == 0, prof
+    eng.close()
