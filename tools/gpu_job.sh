@@ -49,8 +49,10 @@ ablate)
 soak)
   TAG=${1:-x}; SEED=${2:-2}; SP=${3:-300}; SR=${4:-250}; SS=${5:-150}; SN=${6:-80}; O=gpurun_out/soak3_$TAG; mkdir -p $O
   run() { [ $2 -gt 0 ] || return 0; timeout -k 10 $(($2 + 240)) python tests/soak/$1.py $2 $SEED > $O/$1.log 2>&1; echo "$1 exit=$?"; tail -n 1 $O/$1.log; grep MISMATCH $O/$1.log | cut -c1-300 | sed -n 1,4p; }
+  ( while sleep 60; do echo "[soak] $(date +%T) still running"; done ) & HB=$!   # (gpurun takes 7 silent minutes for a hang)
   run fuzz_parity $SP; run fuzz_reuse $SR; run fuzz_stream $SS; run fuzz_sense $SN
   timeout -k 10 300 python tests/soak/edge_inputs.py > $O/edge_inputs.log 2>&1; echo "edge exit=$?"; tail -n 2 $O/edge_inputs.log
+  kill $HB
   true ;;
 evidence)
   CFG=${1:-c2}; PK=${2:-65536}; O=gpurun_out/prof_r3f_$CFG
