@@ -152,9 +152,12 @@ def main():
                     help="receiver front end: 'pn' = the reference's Schmidl-Cox chain (default, the headline number); "
                          "'fixed' = its known-timing test mode (ofdm_receiver.py~:108-119): no filter, no metric -- "
                          "times the rest of the receiver on its own")
-    ap.add_argument("--iq-buffers", type=int, default=1, choices=(1, 2),
-                    help="2: steps alternate two IQ buffers, so that step i+1's modulator may run beside step i's channel "
-                         "filter (the engine orders a transmit batch only behind reads of the buffer it writes)")
+    ap.add_argument("--iq-buffers", type=int, default=None, choices=(1, 2),
+                    help="2: steps alternate two IQ buffers (the engine orders a transmit batch only behind reads of the "
+                         "buffer it writes): step i+1's modulator may run beside step i's channel filter, and beside a "
+                         "receiver that reads its input to the end of the call (fused sensing, SYNC 'fixed': pipelining "
+                         "needs it there).  Default: 2 with --sync fixed, else 1 (at c2 two buffers measure the same, at c5 "
+                         "pipelining measures slower)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="BASELINE.json config to run (default c2 = configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
@@ -210,6 +213,13 @@ def main():
     lens = np.full(P, size, np.uint32)
     nsym, nsamp = eng.tx_frame_count(lens)
     d_blob = torch.from_numpy(blob).to(dev)                       # resident before the timed region
+    # (sense_on is what the configuration says unless --sense overrides it)
+    reads_to_end = (cfgd.get("sense", False) if args.sense == "auto" else args.sense == "on") or args.sync == "fixed"
+    if args.iq_buffers is None:
+        # measured: SYNC 'fixed' at c2 5.05 ms pipelined over two buffers against 5.7 in sequence; c5 (fused sensing)
+        # 9.7-9.8 against 9.45 -- its occupancy-starved kernels lose more to the modulator beside them than the overlap
+        # gains -- so c5 stays in sequence unless --iq-buffers 2 is given
+        args.iq_buffers = 2 if (args.sync == "fixed" and not args.no_pipeline) else 1
     d_iqs = [torch.empty(nsamp * 2, dtype=torch.float32, device=dev) for _ in range(args.iq_buffers)]
     d_out = torch.empty(P * size + 4096, dtype=torch.uint8, device=dev)
     max_pkts = P + 1024
@@ -230,8 +240,9 @@ def main():
     # step's TX is queued as soon as this step's receiver has read the IQ buffer (its input stage, rx_submit) and
     # runs beside the rest of this step's RX, filling the receiver's host round trips.  Every step's TX and RX lie
     # inside the timed region.  With fused sensing (c5) or SYNC 'fixed' the receiver reads the IQ buffer to the end of
-    # the call (the engine refuses a transmit batch into it before that): no overlap.
-    pipelined = not sense_on and args.sync == "pn" and not args.no_pipeline
+    # the call (the engine refuses a transmit batch into it before that): the next batch then goes into a SECOND IQ
+    # buffer (steps alternate two), or there is no overlap.
+    pipelined = not args.no_pipeline and (not reads_to_end or args.iq_buffers >= 2)
 
     def tx(i):
         n = eng.tx_device(d_blob.data_ptr(), offs, lens, d_iqs[i % len(d_iqs)].data_ptr(), nsamp, wait=False)
@@ -369,8 +380,10 @@ def main():
             "config": {"workload": cfgd["name"] + ("" if args.sync == "pn" else " -- SYNC='fixed' test mode (no filter / metric)"),
                        "packets_per_stream_per_step": P, "payload_bytes": size, "symbols_per_packet": nsym // P,
                        "snr_db": args.snr, "streams": world, "iq_buffers": args.iq_buffers, "parallelism": "independent streams, 1 per GPU",
-                       "pipelining": ("TX of step i+1 queued on the handle's transmit stream behind the input stage of "
-                                      "step i's RX" if pipelined else "none (the fused sensor reads the buffer to the end of RX)")},
+                       "pipelining": (("TX of step i+1 queued on the handle's transmit stream behind the input stage of "
+                                       "step i's RX" if not reads_to_end else
+                                       "TX of step i+1 into the other of two IQ buffers, beside step i's RX (which reads its "
+                                       "buffer to the end of the call)") if pipelined else "none (steps in sequence)")},
             "crc_pass_rate": g["crc_ok"] / float(max(world * P * args.steps, 1)),
             "crc_ok_payloads_bit_exact": all_exact,
             # (the synthetic channel's Gaussian is a 16-bit-radius Box-Muller, truncated at 4.85 sigma: pass rates at
