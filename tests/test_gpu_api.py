@@ -160,3 +160,34 @@ def test_frame_acquisition_snr_accessor():
     e = engine.Engine(cfg=make_cfg("qpsk"))
     assert e.snr() == 0.0
     e.close()
+
+
+@pytest.mark.parametrize("extra", [["--config", "c3", "--packets", "512"],
+                                   ["--config", "c5", "--packets", "512"],
+                                   ["--config", "c5", "--packets", "512", "--iq-buffers", "2"],
+                                   ["--sync", "fixed", "--packets", "2048"],
+                                   ["--no-pipeline", "--packets", "2048"]])
+def test_bench_modes_contract(extra):
+    """Every bench configuration / mode (small batches): one JSON line with the contract's keys, the roofline and
+    cpu_baseline objects, every CRC-ok payload bit-exact."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["bench.py", "--steps", "2", "--warmup", "1", "--cpu-packets", "64"] + extra
+    p = subprocess.run([sys.executable] + args, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["vs_baseline"] is None and j["dtype"] == "f32" and j["scaling"] == "weak" and j["value"] > 0
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_rx_matches_on_sample"]
+    assert j["crc_ok_payloads_bit_exact"] and j["crc_pass_rate"] > 0.9
