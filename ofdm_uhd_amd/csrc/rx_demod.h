@@ -375,6 +375,23 @@ __device__ __noinline__ dc dexpj(double ph) {
   return o;
 }
 
+// Per-phase s_memtime stamps of the demodulator (stamps build only: make stamps): thread 0 of every workgroup adds
+// the ticks it spent in each phase to a global table the host prints after the launch.
+#ifdef SYNC_STAMPS
+__device__ unsigned long long g_demod_stamps[16];
+#define DSTAMP(i)                                                        \
+  do {                                                                   \
+    if (threadIdx.x == 0) {                                              \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                \
+      dst_acc[i] += now_ - dst_last;                                     \
+      dst_last = now_;                                                   \
+    }                                                                    \
+  } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
 #ifndef DEMOD_WAVES
 #define DEMOD_WAVES 4  // waves per SIMD the register allocation aims at (114 registers since the preamble phasors left the symbol loop)
 #endif
@@ -467,6 +484,10 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
   }
   frame_sync<FPW>();
 
+#ifdef SYNC_STAMPS
+  unsigned long long dst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dst_last = __builtin_amdgcn_s_memtime();
+#endif
   uint32_t cf = f;  // frame whose symbols are being consumed
   for (;;) {
     const uint32_t j = q_j0 + cf;
@@ -492,6 +513,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
 #pragma unroll
     for (int m = 0; m < 8; m++) nx[m] = q.y[s00 + (uint64_t)(t + m * T)];
 
+    DSTAMP(0);  // frame prologue: flag data, three phasors, first prefetch issued
     dc base = A;  // A * RL^k
     for (uint32_t k = 0; k <= K; k++) {
       if (done && !q.tap_mode) break;
@@ -502,6 +524,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
       c32 e[8];
 #pragma unroll
       for (int m = 0; m < 8; m++) e[m] = nx[m];
+      DSTAMP(6);  // (loop bookkeeping; the wait for the prefetched samples lands in the next phase)
       // ---- sigmix: chan_filt * exp(j phi[n]) ---------------------------------------------
       if (k > 0) {
         base = dmul(base, RL);
@@ -547,6 +570,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
           e[m] = cmul(e[m], mk((float)r.re, (float)r.im));
         }
       }
+      DSTAMP(1);  // derotation (+ the wait for this symbol's samples)
       if (q.tap_sampler) {  // ofdm_receiver-sampler_c.dat: the sampled, derotated symbol
 #pragma unroll
         for (int m = 0; m < 8; m++) q.tap_sampler[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = e[m];
@@ -562,6 +586,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
       } else {
         fft_run<N, false, FftBlockSync, DEMOD_PK>(e, tl, fftbuf, q.tw, FftBlockSync());
       }
+      DSTAMP(2);  // transform
       // the next symbol's samples, in flight during the acquisition / sink half of this one.  (Issued after the
       // transform: its twiddle loads wait on the in-order vector-memory counter, i.e. on everything issued before them.)
       if (k < K) {
@@ -578,6 +603,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
         for (int m = 0; m < 8; m++) q.tap_fft[(symb + k) * (uint64_t)N + (uint64_t)(tl + m * T)] = Ysh[tl + m * T];
       }
 
+      DSTAMP(3);  // next prefetch issued, shifted spectrum to LDS
       // ---- digital_ofdm_frame_acquisition ------------------------------------------------------
       if (k == 0) {
         phase_count = 1;
@@ -658,6 +684,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
         }
       }
 
+      DSTAMP(4);  // frame acquisition (correlation + equaliser on the preamble symbol; the phase term otherwise)
       // ---- digital_ofdm_frame_sink::work ------------------------------------------------------------
       if (done) continue;  // tap pass: the sink is searching again, nothing more to demap in this chain
       if (sstate == 0) {
@@ -735,6 +762,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
         atomicOr(&sbits[bp >> 5], best << (bp & 31));
         if ((bp & 31) + (uint32_t)q.nbits > 32u) atomicOr(&sbits[(bp >> 5) + 1], best >> (32 - (bp & 31)));
       }
+      DSTAMP(5);  // demapper: equalise, rotate, slice, DFE update, bit packing
       if (q.tap_demapped && t == 0) q.tap_demapped[symb + k] = 1;
       block_sum2_f<T>(are, aim, red);
       const float angle = det_atan2f(aim, are);  // arg(accumulated error), bit-reproducible form
@@ -786,6 +814,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
         for (int i = t; i < sbw; i += T) sbits[i] = (i == 0) ? keep : 0u;
         frame_sync<FPW>();
       }
+      DSTAMP(7);  // PLL reduction + update, header parse, message bytes, carry
     }
     if (done) break;
     if (cf + 1 >= q_nframes) break;
@@ -793,6 +822,10 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
   }
   if (!done) end_frame = q_nframes - 1;
 
+#ifdef SYNC_STAMPS
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(&g_demod_stamps[i], dst_acc[i]);
+#endif
   if (!q.tap_mode && t == 0) {
     FrameResult r;
     r.status = status;
