@@ -488,6 +488,7 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
   unsigned long long dst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long dst_last = __builtin_amdgcn_s_memtime();
 #endif
+  const unsigned sidx0 = q.sign_idx[0], sidx1 = q.sign_idx[1], sidx2 = q.sign_idx[2], sidx3 = q.sign_idx[3];  // (scalar registers)
   uint32_t cf = f;  // frame whose symbols are being consumed
   for (;;) {
     const uint32_t j = q_j0 + cf;
@@ -699,7 +700,13 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
       float are = 0.f, aim = 0.f;
       const uint32_t carry_bits = nbits_total & 7u;  // bits of the unfinished byte carried in sbits[0]
       for (int c = t; c < q.nmap; c += T) {
-        const int i = q.smap_lds ? smapL[c] : q.smap[c];
+        // (two typed loads in two branches, not one load through a selected pointer: that would be a FLAT load, whose
+        //  wait also waits for the next symbol's samples in flight)
+        int i;
+        if (q.smap_lds)
+          i = ((const __attribute__((address_space(3))) int16_t*)smapL)[c];
+        else
+          i = ((const __attribute__((address_space(1))) int16_t*)q.smap)[c];
         const int yi = i + q.zl + coarse;
         const c32 Y = (yi >= 0 && yi < N) ? Ysh[yi] : mk(0.f, 0.f);
         const c32 in = cmul(cmul(hinv[i], comp), Y);
@@ -713,9 +720,13 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
         const float sre = fabsf(sigrot.re), sim = fabsf(sigrot.im);
         if (q.sign_kind != 0 && sre > q.sign_eps && sre < q.sign_bound && sim < q.sign_bound &&
             (q.sign_kind == 1 || sim > q.sign_eps)) {
-          const unsigned ix = (q.sign_kind == 1) ? (sigrot.re > 0.0f ? 1u : 0u)
-                                                 : ((sigrot.re > 0.0f ? 2u : 0u) | (sigrot.im > 0.0f ? 1u : 0u));
-          best = q.sign_idx[ix];
+          // (selects between the four scalar entries: indexing the array with a per-lane value would make the
+          //  compiler fetch it from the kernel-argument segment -- a global load, and its wait, per carrier)
+          const bool rp = sigrot.re > 0.0f, ip = sigrot.im > 0.0f;
+          if (q.sign_kind == 1)
+            best = rp ? sidx1 : sidx0;
+          else
+            best = rp ? (ip ? sidx3 : sidx2) : (ip ? sidx1 : sidx0);
         } else if (use_grid && sre <= grid->bound && sim <= grid->bound) {
           int ka = 0, kb = 0;
           for (int a = 1; a < grid->nr - 1; a++) ka += (sigrot.re >= grid->lr[a]) ? 1 : 0;
