@@ -494,66 +494,105 @@ template <int NT, bool KEEP>
 __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, float* me, float* ue, c32* gP, float* gU, long long* sc_i64,
                                                  int amin, int bmax, int D, int CP, int64_t t0s, float tapcp) {
   const int tid = threadIdx.x;
-#define QTERM(m)                                                                   \
-  ([&]() -> Q3 {                                                                   \
-    Q3 q_ = {0, 0, 0};                                                             \
-    const int64_t ia_ = t0s + (int64_t)(m);   /* y before the stream start reads as zero */ \
-    if (ia_ >= 0) {                                                                \
-      const c32 a_ = y[ia_];                                                       \
-      const c32 d_ = ia_ >= D ? y[ia_ - D] : mk(0.f, 0.f);                         \
-      const c32 c_ = cmul_conj(a_, d_);                                            \
-      q_.pr = q40_clamped(c_.re);                                                  \
-      q_.pi = q40_clamped(c_.im);                                                  \
-      q_.r = q40_clamped(a_.re * a_.re + a_.im * a_.im);                           \
-    }                                                                              \
-    return q_;                                                                     \
-  }())
+  // One window term from its two samples (the sample and the one D before it): the correlator product and the energy
+  // in Q23.40.  Samples before the stream start read as zero (a zero sample gives a zero term: the sample D before it
+  // lies before the start as well).
+  auto ldy = [&](int m) -> c32 {
+    const int64_t ia = t0s + (int64_t)m;
+    return ia >= 0 ? y[ia] : mk(0.f, 0.f);
+  };
+  auto qterm = [&](c32 a_, c32 d_) -> Q3 {
+    const c32 c_ = cmul_conj(a_, d_);
+    Q3 q_;
+    q_.pr = q40_clamped(c_.re);
+    q_.pi = q40_clamped(c_.im);
+    q_.r = q40_clamped(a_.re * a_.re + a_.im * a_.im);
+    return q_;
+  };
+  // The loops below fetch the samples of EXACT_G steps before using any of them: one round trip to L2 / HBM per group
+  // instead of one per step (these loads and their waits were most of the kernel: a record is a chain of ~18 of them).
+  constexpr int EXACT_G = 4;
   const int s0 = amin - CP;               // anchor sample (tile-relative, may be negative)
   const int n_e = bmax - s0;              // samples s0+1 .. bmax get an exact M
   const int len = bmax - amin + 1;
   // (i) exact window sums at the anchor
   Q3 an = {0, 0, 0};
-  for (int m = s0 - D + 1 + tid; m <= s0; m += NT) {
-    const Q3 q = QTERM(m);
-    an.pr += q.pr;
-    an.pi += q.pi;
-    an.r += q.r;
+  for (int m0 = s0 - D + 1 + tid; m0 <= s0; m0 += EXACT_G * NT) {
+    c32 ya[EXACT_G], yd[EXACT_G];
+#pragma unroll
+    for (int u = 0; u < EXACT_G; u++) {
+      const int m = m0 + u * NT;
+      const bool on = m <= s0;
+      ya[u] = on ? ldy(m) : mk(0.f, 0.f);
+      yd[u] = on ? ldy(m - D) : mk(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < EXACT_G; u++) {
+      if (m0 + u * NT <= s0) {
+        const Q3 q = qterm(ya[u], yd[u]);
+        an.pr += q.pr;
+        an.pi += q.pi;
+        an.r += q.r;
+      }
+    }
   }
   // (ii) per-thread chunk of the delta sequence, scan, exact M
   const int lc = (n_e + NT - 1) / NT;
   const int k0 = tid * lc, k1 = (k0 + lc < n_e) ? (k0 + lc) : n_e;
-  // A thread's deltas (new term minus the term leaving the window) are needed twice -- for its chunk total before the
-  // scan and again, one by one, after it.  Chunks of up to EXACT_KEEP samples keep them in registers between the two
-  // passes; longer chunks evaluate them again.  KEEP is a template parameter because the 60 registers cost residency:
-  // measured, it pays at N = 4096 (k_sync_exact 1.20 -> 0.89 ms at C5) and loses at N = 2048 / 512 (0.58 -> 0.63,
-  // 0.63 -> 0.69 ms): the host turns it on for D >= 2048.
-  constexpr int EXACT_KEEP = KEEP ? 10 : 1;
+  // the deltas (new term minus the term leaving the window) of steps k .. k + EXACT_G - 1 of this thread's chunk
+  auto deltas = [&](int k, Q3* d) {
+    c32 ya[EXACT_G], yd[EXACT_G], ydd[EXACT_G];
+#pragma unroll
+    for (int u = 0; u < EXACT_G; u++) {
+      const int m = s0 + 1 + k + u;
+      const bool on = k + u < k1;
+      ya[u] = on ? ldy(m) : mk(0.f, 0.f);
+      yd[u] = on ? ldy(m - D) : mk(0.f, 0.f);
+      ydd[u] = on ? ldy(m - 2 * D) : mk(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < EXACT_G; u++) {
+      const Q3 a = qterm(ya[u], yd[u]), b = qterm(yd[u], ydd[u]);
+      d[u].pr = a.pr - b.pr;
+      d[u].pi = a.pi - b.pi;
+      d[u].r = a.r - b.r;
+    }
+  };
+  // A thread's deltas are needed twice -- for its chunk total before the scan and again, one by one, after it.  Chunks
+  // of up to EXACT_KEEP samples keep them in registers between the two passes; longer chunks evaluate them again.
+  // KEEP is a template parameter because the registers cost residency: measured, it pays at N = 4096 (k_sync_exact
+  // 1.20 -> 0.89 ms at C5) and loses at N = 2048 / 512 (0.58 -> 0.63, 0.63 -> 0.69 ms): the host turns it on for
+  // D >= 2048.
+#ifndef EXACT_KEEP_N
+#define EXACT_KEEP_N 12  // (a multiple of EXACT_G)
+#endif
+  constexpr int EXACT_KEEP = KEEP ? EXACT_KEEP_N : EXACT_G;
   const bool keep = KEEP && lc <= EXACT_KEEP;
   Q3 dq[EXACT_KEEP];
   Q3 tq = {0, 0, 0};
   if (keep) {
 #pragma unroll
+    for (int i = 0; i < EXACT_KEEP; i += EXACT_G) deltas(k0 + i, dq + i);
+#pragma unroll
     for (int i = 0; i < EXACT_KEEP; i++) {
-      Q3 d = {0, 0, 0};
       if (k0 + i < k1) {
-        const int m = s0 + 1 + k0 + i;
-        const Q3 a = QTERM(m), b = QTERM(m - D);
-        d.pr = a.pr - b.pr;
-        d.pi = a.pi - b.pi;
-        d.r = a.r - b.r;
+        tq.pr += dq[i].pr;
+        tq.pi += dq[i].pi;
+        tq.r += dq[i].r;
       }
-      dq[i] = d;
-      tq.pr += d.pr;
-      tq.pi += d.pi;
-      tq.r += d.r;
     }
   } else {
-    for (int k = k0; k < k1; k++) {
-      const int m = s0 + 1 + k;
-      const Q3 a = QTERM(m), b = QTERM(m - D);
-      tq.pr += a.pr - b.pr;
-      tq.pi += a.pi - b.pi;
-      tq.r += a.r - b.r;
+    for (int k = k0; k < k1; k += EXACT_G) {
+      Q3 d[EXACT_G];
+      deltas(k, d);
+#pragma unroll
+      for (int u = 0; u < EXACT_G; u++) {
+        if (k + u < k1) {
+          tq.pr += d[u].pr;
+          tq.pi += d[u].pi;
+          tq.r += d[u].r;
+        }
+      }
     }
   }
   Q3 ex, ansum;
@@ -579,14 +618,12 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
     for (int i = 0; i < EXACT_KEEP; i++)
       if (k0 + i < k1) emit(k0 + i, dq[i]);
   } else {
-    for (int k = k0; k < k1; k++) {
-      const int m = s0 + 1 + k;
-      const Q3 a = QTERM(m), b = QTERM(m - D);
-      Q3 d;
-      d.pr = a.pr - b.pr;
-      d.pi = a.pi - b.pi;
-      d.r = a.r - b.r;
-      emit(k, d);
+    for (int k = k0; k < k1; k += EXACT_G) {
+      Q3 d[EXACT_G];
+      deltas(k, d);
+#pragma unroll
+      for (int u = 0; u < EXACT_G; u++)
+        if (k + u < k1) emit(k + u, d[u]);
     }
   }
   __syncthreads();
@@ -609,7 +646,6 @@ __device__ __forceinline__ void sync_exact_range(const c32* __restrict__ y, floa
     if (gU) gU[jj] = ux;
   }
   __syncthreads();
-#undef QTERM
 }
 
 #ifdef SYNC_STAMPS
@@ -1255,10 +1291,20 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
     const int j0 = tl * lc, j1 = (j0 + lc < rlen) ? (j0 + lc) : rlen;
     long long xq = 0;
     int nstart = 0;
-    for (int k = j0; k < j1; k++) {
-      const float ux = ue[k];
-      xq += q40_from_double((alpha_d * (double)ux) * p.dpow[Tl - 1 - (amin + k)]);
-      if (ux > p.cand_thr && !(k > 0 && ue[k - 1] > p.cand_thr)) nstart++;
+    // (the weights of four steps are fetched together: one round trip to the table per group, not per step)
+    for (int kg = j0; kg < j1; kg += 4) {
+      double dw[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) dw[u] = (kg + u < j1) ? p.dpow[Tl - 1 - (amin + kg + u)] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = kg + u;
+        if (k < j1) {
+          const float ux = ue[k];
+          xq += q40_from_double((alpha_d * (double)ux) * dw[u]);
+          if (ux > p.cand_thr && !(k > 0 && ue[k - 1] > p.cand_thr)) nstart++;
+        }
+      }
     }
     Q3 v3 = {xq, (long long)nstart, 0}, ex, tot;
     block_scan3_sum3_i64<NT>(v3, v3, sc_i64, &ex, &tot);
@@ -1275,21 +1321,30 @@ __global__ void __launch_bounds__(NT) k_sync_exact(SyncParams p) {
     if (fits && npieces > 0) {
       long long X = ex.pr;  // the range's samples before this thread's first
       int so = (int)ex.pi;
-      for (int k = j0; k < j1; k++) {
-        const float ux = ue[k];
-        const bool cand = ux > p.cand_thr;
-        const uint64_t n = t0 + (uint64_t)(amin + k);
-        if (cand && !(k > 0 && ue[k - 1] > p.cand_thr)) {
-          SyncPiece* pc = p.pieces + basep + so;
-          pc->start = n;
-          pc->val_off = cbase + (unsigned long long)k;
-          // the average (zero at the tile start) just before this sample: everything before it, weighted to the tile's
-          // end, carried back by 1 / decay^(Tl - s)
-          pc->bloc = ((double)rec.gpre + (double)X * Q40_INV) * p.ipow[Tl - (amin + k)];
-          so++;
+      for (int kg = j0; kg < j1; kg += 4) {
+        double dw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) dw[u] = (kg + u < j1) ? p.dpow[Tl - 1 - (amin + kg + u)] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = kg + u;
+          if (k < j1) {
+            const float ux = ue[k];
+            const bool cand = ux > p.cand_thr;
+            const uint64_t n = t0 + (uint64_t)(amin + k);
+            if (cand && !(k > 0 && ue[k - 1] > p.cand_thr)) {
+              SyncPiece* pc = p.pieces + basep + so;
+              pc->start = n;
+              pc->val_off = cbase + (unsigned long long)k;
+              // the average (zero at the tile start) just before this sample: everything before it, weighted to the
+              // tile's end, carried back by 1 / decay^(Tl - s)
+              pc->bloc = ((double)rec.gpre + (double)X * Q40_INV) * p.ipow[Tl - (amin + k)];
+              so++;
+            }
+            if (cand && !(k + 1 < rlen && ue[k + 1] > p.cand_thr)) p.pieces[basep + so - 1].end = n;
+            X += q40_from_double((alpha_d * (double)ux) * dw[u]);
+          }
         }
-        if (cand && !(k + 1 < rlen && ue[k + 1] > p.cand_thr)) p.pieces[basep + so - 1].end = n;
-        X += q40_from_double((alpha_d * (double)ux) * p.dpow[Tl - 1 - (amin + k)]);
       }
     }
     if (tl == 0) {
