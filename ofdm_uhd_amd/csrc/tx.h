@@ -277,9 +277,26 @@ __global__ void __launch_bounds__(TxGeom<N>::WG, TX_WAVES)
   // a chain of three dependent global loads.
   c32* twl = reinterpret_cast<c32*>(smem_raw) + SPW * TxGeom<N>::SYM_POINTS;  // twiddle table, shared by the workgroup
   c32* cst = twl + TxGeom<N>::TW_POINTS;                                       // [arity], shared by the workgroup
-  for (int i = threadIdx.x; i < p.arity; i += TxGeom<N>::WG) cst[i] = p.constellation[i];
-  if constexpr (TxGeom<N>::TW_LDS)
-    for (int i = threadIdx.x; i < fft_tw_used(N); i += TxGeom<N>::WG) twl[lpad(i)] = p.tw[i];
+  // The tables' loads are issued here and their values parked in registers; they go to LDS further down, after the
+  // message slice's loads have been issued too: the wave waits for ONE round trip to memory, not for one per table
+  // (a wave lives for one symbol: this prologue is most of its life).
+  constexpr int CSTN = (OFDM_MAX_ARITY + TxGeom<N>::WG - 1) / TxGeom<N>::WG;
+  constexpr int TWN = TxGeom<N>::TW_LDS ? (fft_tw_used(N) + TxGeom<N>::WG - 1) / TxGeom<N>::WG : 0;
+  c32 cst_v[CSTN], tw_v[TWN > 0 ? TWN : 1];
+#pragma unroll
+  for (int r = 0; r < CSTN; r++) {
+    const int i = (int)threadIdx.x + r * TxGeom<N>::WG;
+    cst_v[r] = p.constellation[i < p.arity ? i : p.arity - 1];  // (clamped, not predicated: a predicated load is waited for at once)
+  }
+#pragma unroll
+  for (int r = 0; r < TWN; r++) {
+    const int i = (int)threadIdx.x + r * TxGeom<N>::WG;
+    tw_v[r] = p.tw[i < fft_tw_used(N) ? i : fft_tw_used(N) - 1];
+  }
+  // (the carrier of every bin this thread transforms: independent of the message, so in flight with it)
+  int car[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) car[m] = p.bin2car[(t + m * T + N / 2) & (N - 1)];  // ifftshift folded into the index
   uint32_t* mbytes = reinterpret_cast<uint32_t*>(lds);  // this symbol's message bytes (<= N + 8 of them)
   const uint32_t nb = (uint32_t)p.nbits, bmask = (1u << nb) - 1u;
   const uint8_t* msg = framed + framed_off[pkt];
@@ -297,16 +314,23 @@ __global__ void __launch_bounds__(TxGeom<N>::WG, TX_WAVES)
     const uint32_t ndw = (sh + (bend - byte0) + 3u) >> 2;
     for (uint32_t d = (uint32_t)t; d < ndw; d += T) mbytes[d] = base[d];
   }
-  __syncthreads();  // (the constellation is shared by the workgroup's symbols)
+#pragma unroll
+  for (int r = 0; r < CSTN; r++) {
+    const int i = (int)threadIdx.x + r * TxGeom<N>::WG;
+    if (i < p.arity) cst[i] = cst_v[r];
+  }
+#pragma unroll
+  for (int r = 0; r < TWN; r++) {
+    const int i = (int)threadIdx.x + r * TxGeom<N>::WG;
+    if (i < fft_tw_used(N)) twl[lpad(i)] = tw_v[r];
+  }
+  __syncthreads();  // (the tables are shared by the workgroup's symbols)
   c32 e[8];
   if (s == 0) {
     // ofdm_insert_preamble: the known symbol goes out ahead of the packet's first symbol
 #pragma unroll
     for (int m = 0; m < 8; m++) e[m] = p.preamble[(t + m * T + N / 2) & (N - 1)];
   } else {
-    int car[8];
-#pragma unroll
-    for (int m = 0; m < 8; m++) car[m] = p.bin2car[(t + m * T + N / 2) & (N - 1)];  // ifftshift folded into the index
     const uint8_t* mb8 = reinterpret_cast<const uint8_t*>(mbytes);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
