@@ -687,10 +687,19 @@ __global__ void __launch_bounds__(((N / 8 < 64) ? 64 : N / 8) * demod_fpw(N), de
 
       DSTAMP(4);  // frame acquisition (correlation + equaliser on the preamble symbol; the phase term otherwise)
       // ---- digital_ofdm_frame_sink::work ------------------------------------------------------------
-      if (done) continue;  // tap pass: the sink is searching again, nothing more to demap in this chain
+      // The symbol may end right here (preamble symbol; tap pass behind the end of the packet).  The next symbol's
+      // transform then overwrites Ysh: in a frame of several waves a wave that is done with its share of the FFT /
+      // acquisition taps must not get there while another still reads.  (Soak K3, seed 81: one acq-tap mismatch in
+      // 16 162 cases, at N = 4096, which a replay of the same sequence did not show -- a race, found by reading for it.
+      // `done` and `sstate` are the same in every thread of the frame.)
+      if (done) {  // tap pass: the sink is searching again, nothing more to demap in this chain
+        frame_sync<FPW>();
+        continue;
+      }
       if (sstate == 0) {
         // only reachable on the chain's first symbol (a preamble): enter_have_sync
         sstate = 1;
+        frame_sync<FPW>();
         continue;
       }
       // demapper

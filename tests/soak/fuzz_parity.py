@@ -138,7 +138,15 @@ while time.time() < t_end:
         nbad += 1
         if os.environ.get("FUZZ_STOP"):
             t_end = 0
-        print("MISMATCH [%s]" % (e if isinstance(e, AssertionError) else "error " + str(e)[:80]), json.dumps(desc), flush=True)
+        print("MISMATCH [%s] case %d" % (e if isinstance(e, AssertionError) else "error " + str(e)[:80], ncase), json.dumps(desc), flush=True)
+        # keep what is needed to replay the case without the random sequence that led to it
+        try:
+            out = os.path.join(ROOT, "gpurun_out", "fuzz_parity_fail_%d_%d.npz" % (seed, ncase))
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            np.savez_compressed(out, x=x, desc=json.dumps(desc), payloads=np.array([p.hex() for p in pay]))
+            print("   capture saved to", out, flush=True)
+        except Exception as e2:
+            print("   (capture not saved: %s)" % e2, flush=True)
     finally:
         eng.close()
 print("fuzz: %d cases, %d mismatches, seed %d (captures on which the literal recurrence differs: %d; with a pre-selection miss: %d)" % (
