@@ -1435,47 +1435,47 @@ __global__ void __launch_bounds__(256) k_peak(PeakParams p) {
     for (;;) {
       const uint32_t len = (uint32_t)(pc.end - pc.start + 1);  // a piece lies inside one tile
       const float* __restrict__ up = p.cand_u + pc.val_off;
-      for (uint32_t kb = 0; kb < len; kb += 8) {
-        // eight values per trip: the loads are independent of the state machine, so issue them together
+      // gr_peak_detector_fb's automaton on one value, without branches on the common paths:
+      //   searching: u > avg*rise opens a run, and the value is then looked at as the run's first;
+      //   in a run: a new maximum is recorded; else u > avg*fall keeps the run; else the run ends -- a flag at
+      //   the recorded maximum -- and the SAME value is looked at again by the searching detector.
+      // The average moves exactly once per value on every path.
+      auto step = [&](const float u, const uint32_t k) __attribute__((always_inline)) {
+        bool s1 = (state != 0) || (u > avg * p.rise);
+        bool newpk = s1 && (u > peak_val);
+        if (s1 && !newpk && !(u > avg * p.fall)) {  // the run ends here (once per run)
+          const uint64_t ind = pk_cur ? pc.start + pk_k : peak_ind;
+          const uint64_t off = pk_cur ? pc.val_off + pk_k : peak_off;
+          if (WRITE) {
+            p.peaks[wbase + nflag] = ind;
+            p.peak_P[wbase + nflag] = p.cand_P[off];
+          } else if (nflag < PEAK_STASH) {
+            p.stash_peaks[g0 * PEAK_STASH + nflag] = ind;
+            p.stash_P[g0 * PEAK_STASH + nflag] = p.cand_P[off];
+          }
+          nflag++;
+          peak_val = -INFINITY;
+          pk_cur = false;
+          s1 = u > avg * p.rise;
+          newpk = s1 && (u > peak_val);
+        }
+        peak_val = newpk ? u : peak_val;
+        pk_k = newpk ? k : pk_k;
+        pk_cur = pk_cur || newpk;
+        avg = p.alpha * u + one_m_alpha * avg;
+        state = s1 ? 1 : 0;
+      };
+      // eight values per trip (the loads are independent of the state machine: issued together); whole trips carry
+      // no per-value bounds test, the piece's last values are taken one by one
+      uint32_t kb = 0;
+      for (; kb + 8 <= len; kb += 8) {
         float ub[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) ub[e] = up[(kb + e < len) ? kb + e : len - 1];
+        for (int e = 0; e < 8; e++) ub[e] = up[kb + e];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          const uint32_t k = kb + e;
-          if (k < len) {
-            // gr_peak_detector_fb's automaton on one value, without branches on the common paths:
-            //   searching: u > avg*rise opens a run, and the value is then looked at as the run's first;
-            //   in a run: a new maximum is recorded; else u > avg*fall keeps the run; else the run ends -- a flag at
-            //   the recorded maximum -- and the SAME value is looked at again by the searching detector.
-            // The average moves exactly once per value on every path.
-            const float u = ub[e];
-            bool s1 = (state != 0) || (u > avg * p.rise);
-            bool newpk = s1 && (u > peak_val);
-            if (s1 && !newpk && !(u > avg * p.fall)) {  // the run ends here (once per run)
-              const uint64_t ind = pk_cur ? pc.start + pk_k : peak_ind;
-              const uint64_t off = pk_cur ? pc.val_off + pk_k : peak_off;
-              if (WRITE) {
-                p.peaks[wbase + nflag] = ind;
-                p.peak_P[wbase + nflag] = p.cand_P[off];
-              } else if (nflag < PEAK_STASH) {
-                p.stash_peaks[g0 * PEAK_STASH + nflag] = ind;
-                p.stash_P[g0 * PEAK_STASH + nflag] = p.cand_P[off];
-              }
-              nflag++;
-              peak_val = -INFINITY;
-              pk_cur = false;
-              s1 = u > avg * p.rise;
-              newpk = s1 && (u > peak_val);
-            }
-            peak_val = newpk ? u : peak_val;
-            pk_k = newpk ? k : pk_k;
-            pk_cur = pk_cur || newpk;
-            avg = p.alpha * u + one_m_alpha * avg;
-            state = s1 ? 1 : 0;
-          }
-        }
+        for (int e = 0; e < 8; e++) step(ub[e], kb + e);
       }
+      for (; kb < len; kb++) step(up[kb], kb);
       if (pk_cur) {
         peak_ind = pc.start + pk_k;
         peak_off = pc.val_off + pk_k;
