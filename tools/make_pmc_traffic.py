@@ -26,9 +26,11 @@ KERNELS = {"k_frame_pack": "k_frame_pack", "k_tx_mod": "k_tx_mod", "k_chan_filte
 
 
 def per_kernel(path, counter):
-    fs = glob.glob(path + "/*/*_counter_collection.csv")
+    # (a scratch directory may hold the files of several runs: the newest one with counters in it)
+    fs = sorted(glob.glob(path + "/*/*_counter_collection.csv"), key=os.path.getmtime)
+    fs = [f for f in fs if os.path.getsize(f) > 1000]
     tot, steps = collections.defaultdict(float), 0
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(fs[-1])):
         if r["Counter_Name"] != counter:
             continue
         if "k_rx_demod" in r["Kernel_Name"]:
