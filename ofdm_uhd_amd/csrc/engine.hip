@@ -722,9 +722,15 @@ static void launch_tx_mod(ofdm_handle* h, const TxParams& p, const uint8_t* d_fr
   constexpr int SPW = TxGeom<N>::SPW, WG = TxGeom<N>::WG;
   const size_t shmem = (size_t)TxGeom<N>::lds_bytes();  // transforms' buffers | constellation
   const unsigned grid = (unsigned)((nsym + SPW - 1) / SPW);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N>), dim3(grid), dim3(WG), shmem, h->txs, p, d_framed,
-                     h->d_framed_off.as<uint64_t>(), h->d_sym_off.as<uint64_t>(), h->d_sym_pkt.as<uint32_t>(),
-                     uniform_spp, nsym, lead, d_out, d_freq_tap, d_ifft_tap);
+  // (a batch without transmit-side taps and without a carrier offset runs the kernel compiled without them: tx.h)
+  if (!d_freq_tap && !d_ifft_tap && !(p.chan_on && p.cfo != 0.0f))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N, true>), dim3(grid), dim3(WG), shmem, h->txs, p, d_framed,
+                       h->d_framed_off.as<uint64_t>(), h->d_sym_off.as<uint64_t>(), h->d_sym_pkt.as<uint32_t>(),
+                       uniform_spp, nsym, lead, d_out, d_freq_tap, d_ifft_tap);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tx_mod<N, false>), dim3(grid), dim3(WG), shmem, h->txs, p, d_framed,
+                       h->d_framed_off.as<uint64_t>(), h->d_sym_off.as<uint64_t>(), h->d_sym_pkt.as<uint32_t>(),
+                       uniform_spp, nsym, lead, d_out, d_freq_tap, d_ifft_tap);
 }
 
 static int launch_noise(ofdm_handle* h, hipStream_t st, c32* d_iq, uint64_t n, uint64_t index0, int zero_input, const ofdm_chan& ch) {
